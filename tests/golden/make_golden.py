@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the compiled reference.
+
+Runs only in the build container (needs oracle/_ref/emsar and emsar-build, which
+oracle/Makefile compiles from /root/reference/src).  The fixtures are DATA: our own
+synthetic inputs (FASTA / rsh text / default-bowtie text) plus the files the reference
+wrote for them (.fpkm, .segments, .fraglength_effect).  Nothing of the reference's
+source is stored.
+
+Every case is run RUNS times because the reference seeds rand() with time(NULL)
+(emsar_main.c:441) and disagrees with itself in the last digits;
+run 0 keeps all three outputs, later runs keep the .fpkm only (noise mask).
+
+    python tests/golden/make_golden.py [case ...]
+"""
+import gzip
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF_EMSAR = os.path.join(ROOT, "oracle", "_ref", "emsar")
+REF_BUILD = os.path.join(ROOT, "oracle", "_ref", "emsar-build")
+FIXED_TIME = os.path.join(ROOT, "oracle", "_ref", "libfixedtime.so")
+RUNS = 3
+SEED = 12345
+
+
+def rand_seq(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def bowtie_line(rid, strand, tname, pos, fraglen, mm=""):
+    # default bowtie output: name, strand, ref, 0-based offset, seq, qual, other-count, mismatches.
+    # The reference reads fields 1-5 and 8 only; the LENGTH of field 5 is the fragment length
+    # (emsar_functions.c:565-573).
+    return "%s\t%s\t%s\t%d\t%s\t%s\t0\t%s\n" % (rid, strand, tname, pos, "A" * fraglen, "I" * fraglen, mm)
+
+
+def gzip_inplace(path):
+    # the reference reads plain text; fixtures are stored gzipped (mtime=0 for reproducible bytes)
+    with open(path, "rb") as fi, open(path + ".gz", "wb") as raw:
+        with gzip.GzipFile(filename="", mode="wb", compresslevel=9, fileobj=raw, mtime=0) as fo:
+            shutil.copyfileobj(fi, fo)
+    os.remove(path)
+
+
+def run_reference(case_dir, rsh, aln, extra_opts, runs=RUNS):
+    out = os.path.join(case_dir, "_out")
+    for r in range(runs):
+        shutil.rmtree(out, ignore_errors=True)
+        cmd = [REF_EMSAR, "-q", "-g"] + extra_opts + ["-I", rsh, out, "ref", aln]
+        t0 = time.time()
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.time() - t0
+        if r == 0:
+            for ext in ("fpkm", "segments", "fraglength_effect"):
+                shutil.copy(os.path.join(out, "ref.0." + ext), os.path.join(case_dir, "ref.run0." + ext))
+        else:
+            shutil.copy(os.path.join(out, "ref.0.fpkm"), os.path.join(case_dir, "ref.run%d.fpkm" % r))
+        print("  run %d: %.1fs" % (r, dt))
+        time.sleep(1.1)  # new time(NULL) seed for the next run
+    # seeded run: time() pinned by oracle/_ref/libfixedtime.so, one thread -> rand() stream reproducible.
+    # Pins oracle_mle_pattern_search bit-for-bit (tests/test_oracle_golden.py).
+    shutil.rmtree(out, ignore_errors=True)
+    env = dict(os.environ, LD_PRELOAD=FIXED_TIME, EMSAR_FIXED_TIME=str(SEED))
+    scmd = [REF_EMSAR, "-q"] + extra_opts + ["-p", "1", "-I", rsh, out, "ref", aln]
+    subprocess.run(scmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+    shutil.copy(os.path.join(out, "ref.0.fpkm"), os.path.join(case_dir, "ref.seed%d.fpkm" % SEED))
+    shutil.rmtree(out, ignore_errors=True)
+    return cmd
+
+
+# ----------------------------------------------------------------------------------------------
+# case 1: 5 transcripts, real emsar-build index (exercises internal repeats "2,4,4")
+# ----------------------------------------------------------------------------------------------
+def case_toy5(case_dir):
+    rng = random.Random(7)
+    ex = [rand_seq(rng, 120) for _ in range(6)]
+    tx = [("tA", ex[0] + ex[1] + ex[2]), ("tB", ex[0] + ex[2]), ("tC", ex[3] + ex[1] + ex[4]),
+          ("tD", ex[5]), ("tE", ex[3] + ex[4] + ex[3])]
+    L = 50
+    with open(os.path.join(case_dir, "tx.fa"), "w") as f:
+        for n, s in tx:
+            f.write(">%s\n%s\n" % (n, s))
+    subprocess.run([REF_BUILD, "-q", os.path.join(case_dir, "tx.fa"), str(L), case_dir, "index"],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # exact alignments: every (tid,pos) where the 50-mer occurs on the forward strand
+    occ = {}
+    for n, s in tx:
+        for p in range(len(s) - L + 1):
+            occ.setdefault(s[p:p + L], []).append((n, p))
+    abund = {"tA": 30.0, "tB": 12.0, "tC": 7.0, "tD": 0.0, "tE": 3.0}
+    starts = [(n, p) for n, s in tx for p in range(len(s) - L + 1) for _ in range(1)]
+    weights = [abund[n] for n, p in starts]
+    n_reads = 3000
+    lines = []
+    seqs = dict(tx)
+    for i in range(n_reads):
+        n, p = rng.choices(starts, weights)[0]
+        kmer = seqs[n][p:p + L]
+        hits = occ[kmer]
+        for (hn, hp) in hits:
+            lines.append(bowtie_line("r%d" % i, "+", hn, hp, L))
+        if i % 500 == 0:  # consecutive duplicate record: dropped by alignment.c:37-41
+            lines.append(bowtie_line("r%d" % i, "+", hits[0][0], hits[0][1], L))
+        if i % 700 == 1:  # a worse (1-mismatch) extra hit on tD: dropped by the best-mm filter
+            lines.append(bowtie_line("r%d" % i, "+", "tD", 3, L, "10:A>C"))
+    aln = os.path.join(case_dir, "reads.bowtie")
+    with open(aln, "w") as f:
+        f.writelines(lines)
+    cmd = run_reference(case_dir, os.path.join(case_dir, "index.rsh"), aln, [])
+    gzip_inplace(aln)
+    return {"n_reads_emitted": n_reads, "total_read_count": n_reads, "opts": [], "cmd": " ".join(cmd)}
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic rsh written directly (format: emsar_functions.c:2085-2127)
+# ----------------------------------------------------------------------------------------------
+def synth_rsh_case(case_dir, seed, n_tx, minfrag, maxfrag, n_reads, opts, fam_max=6,
+                   n_orphans=20, n_badlen=15, with_quirks=True):
+    rng = random.Random(seed)
+    nfl = maxfrag - minfrag + 1
+    names = ["ENST%07d" % (1000 + i) for i in range(n_tx)]
+    # families of consecutive tids
+    fams, t = [], 0
+    while t < n_tx:
+        k = min(n_tx - t, rng.choice([1, 1, 1, 2, 2, 3, 4, fam_max]))
+        fams.append(list(range(t, t + k)))
+        t += k
+    singles = {}       # tid -> EUMA list (or None: no unique region)
+    multis = {}        # tuple(sorted tids with repeats) -> EUMA list
+
+    def euma_vec(base):
+        # effective count per fragment length: shrinks by one position per extra base
+        return [max(0, base - i) for i in range(nfl)]
+
+    for fam in fams:
+        for tid in fam:
+            if with_quirks and len(fam) > 1 and rng.random() < 0.15:
+                singles[tid] = None                      # no unique region -> empty EUMA row
+            else:
+                singles[tid] = euma_vec(rng.randint(30, 1500))
+        if len(fam) > 1:
+            n_sub = rng.randint(1, min(6, 2 ** len(fam) - len(fam) - 1))
+            for _ in range(n_sub):
+                k = rng.randint(2, len(fam))
+                sub = sorted(rng.sample(fam, k))
+                if with_quirks and rng.random() < 0.1:  # internal repeat: a tid listed twice
+                    sub = sorted(sub + [rng.choice(sub)])
+                multis[tuple(sub)] = euma_vec(rng.randint(20, 900))
+    if with_quirks:
+        # cross-family segments
+        for _ in range(max(1, n_tx // 40)):
+            a, b = rng.sample(range(n_tx), 2)
+            multis[tuple(sorted((a, b)))] = euma_vec(rng.randint(20, 200))
+        # a tied pair: two transcripts that only ever occur together (identical columns)
+        a = fams[-1][0]
+        if len(fams[-1]) >= 2:
+            b = fams[-1][1]
+            for key in [k for k in multis if (a in k) != (b in k)]:
+                del multis[key]
+            singles[a] = None
+            singles[b] = None
+            multis[(a, b)] = euma_vec(400)
+        # a multi segment whose EUMA is zero at every length -> E_c = 0 row
+        f0 = next(f for f in fams if len(f) >= 2)
+        multis[tuple(f0[:2])] = [0] * nfl
+    max_t = max([len(k) for k in multis] + [1])
+
+    rsh = os.path.join(case_dir, "index.rsh")
+    with open(rsh, "w") as f:
+        f.write("#%d,%d,%d,%d,%d\n" % (n_tx - 1, max_t, minfrag, maxfrag, -1))
+        for i, n in enumerate(names):
+            f.write("@%d\t%s\n" % (i, n))
+        f.write("cid\tno.tids\tfirst.tid\tother.tids\tsegment.length\n")
+        cid = 0
+        for tid in range(n_tx):
+            e = singles[tid]
+            if e is None:
+                f.write("%d\t1\t%d\t\t\t\n" % (cid, tid))
+            else:
+                f.write("%d\t1\t%d\t\t%s\n" % (cid, tid, "".join("%d," % x for x in e)))
+            cid += 1
+        for size in range(2, max_t + 1):
+            keys = sorted(k for k in multis if len(k) == size)
+            for k in keys:
+                f.write("%d\t%d\t%d\t%s\t%s\n" % (cid, size, k[0], "".join("%d," % x for x in k[1:]),
+                                                  "".join("%d," % x for x in multis[k])))
+                cid += 1
+
+    # true abundances: log-normal with 30 % zeros; some whole families silent (zero-count sets)
+    theta = [0.0 if rng.random() < 0.3 else rng.lognormvariate(0, 2) for _ in range(n_tx)]
+    for fam in fams[::7]:
+        for tid in fam:
+            theta[tid] = 0.0
+    flw = [rng.random() + 0.2 for _ in range(nfl)]
+    segs = [((tid,), e) for tid, e in singles.items() if e is not None] + list(multis.items())
+    choices, weights = [], []
+    for key, e in segs:
+        s = sum(theta[t] for t in key)
+        for i in range(nfl):
+            w = e[i] * flw[i] * s
+            if w > 0:
+                choices.append((key, i))
+                weights.append(w)
+    picks = rng.choices(choices, weights, k=n_reads)
+    lines = []
+    n_total = 0
+    kmax = int(opts[opts.index("-k") + 1]) if "-k" in opts else 100
+    for r, (key, i) in enumerate(picks):
+        fl = minfrag + i
+        order = list(key)
+        rng.shuffle(order)                      # alignment order is arbitrary; the collapse sorts
+        for j, tid in enumerate(order):
+            lines.append(bowtie_line("r%d" % r, "+", names[tid], 10 + 7 * j, fl))
+        n_total += len(order) <= kmax           # reads over -k are discarded, not counted (emsar_functions.c:752)
+    # reads whose tid-set has no rsh node: counted in N, not in any R_c
+    for r in range(n_orphans):
+        a, b, c = rng.sample(range(n_tx), 3)
+        for j, tid in enumerate((a, b, c)):
+            lines.append(bowtie_line("orph%d" % r, "+", names[tid], 5 + j, minfrag))
+        n_total += 3 <= kmax
+    # reads with a fragment length outside [min,max]: dropped entirely (emsar_functions.c:849)
+    for r in range(n_badlen):
+        lines.append(bowtie_line("short%d" % r, "+", names[r % n_tx], 1, minfrag - 1))
+    aln = os.path.join(case_dir, "reads.bowtie")
+    with open(aln, "w") as f:
+        f.writelines(lines)
+    cmd = run_reference(case_dir, rsh, aln, opts)
+    gzip_inplace(aln)
+    return {"n_reads_emitted": n_reads + n_orphans + n_badlen, "total_read_count": n_total,
+            "opts": opts, "cmd": " ".join(cmd), "true_theta_nonzero": sum(1 for x in theta if x > 0)}
+
+
+CASES = {
+    "toy5_se50": case_toy5,
+    "syn300_se": lambda d: synth_rsh_case(d, seed=11, n_tx=300, minfrag=40, maxfrag=44, n_reads=6000, opts=[]),
+    "syn300_k2": lambda d: synth_rsh_case(d, seed=12, n_tx=300, minfrag=36, maxfrag=36, n_reads=4000,
+                                          opts=["-k", "2"]),
+    "syn2k_se": lambda d: synth_rsh_case(d, seed=13, n_tx=2000, minfrag=50, maxfrag=52, n_reads=40000,
+                                         opts=["-p", "4"]),
+}
+
+
+def main():
+    if not (os.path.exists(REF_EMSAR) and os.path.exists(REF_BUILD)):
+        sys.exit("build the reference first: make -C oracle ref")
+    todo = sys.argv[1:] or list(CASES)
+    for name in todo:
+        d = os.path.join(HERE, name)
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d)
+        print("case", name)
+        meta = CASES[name](d)
+        meta["case"] = name
+        meta["runs"] = RUNS
+        meta["seed"] = SEED
+        meta["cmd"] = meta["cmd"].replace(ROOT + "/", "")
+        with open(os.path.join(d, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
