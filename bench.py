@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- EM iterations/s of the HIP abundance core on BASELINE.json's headline workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3] [--scale 1.0]
+
+A "step" is one EM pass (E-step + M-step) over one synthetic read->transcript compatibility matrix that is
+already resident in HBM.  N=1: BASELINE config 3 (50M reads x 200k transcripts, mean 5 alignments, -k 100).
+N>1 (torchrun, one rank per GPU): the -M multi-sample path -- every rank solves its OWN independent sample
+of the same shape (different seed), no data-path collective; weak scaling.  The only torch.distributed use
+is the barrier and the max-over-ranks of the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel k_pass_windowed (+ the small k_update
+that shares the pass): algorithmic bytes per pass / mean device time per pass measured with
+HIP events on the library's own stream.  `cpu_baseline` times the CPU oracle's OpenMP EM pass on the same
+matrix on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink reads and transcripts (debug only)")
+    ap.add_argument("--layout", default="auto", choices=["auto", "csr", "windowed"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    import torch
+    from emsar_amd import EmsarHip, synth
+    from emsar_amd.hip import LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_WINDOWED
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload: one independent sample per rank ------------------------------------------------------
+    cfg = dict(synth.CONFIGS[args.config])
+    cfg["seed"] = cfg["seed"] + 100 * rank
+    if args.scale != 1.0:
+        cfg["n_reads"] = max(1000, int(cfg["n_reads"] * args.scale))
+        cfg["n_tx"] = max(500, int(cfg["n_tx"] * args.scale))
+    t0 = time.time()
+    s = synth.make_matrix(**cfg)
+    t_gen = time.time() - t0
+    nnz = int(len(s["col_idx"]))
+    layout = {"auto": LAYOUT_AUTO, "csr": LAYOUT_CSR, "windowed": LAYOUT_WINDOWED}[args.layout]
+    dev = EmsarHip(local_rank)
+    t0 = time.time()
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], layout)
+    dev.upload_sample(None, None, s["den"])
+    t_up = time.time() - t0
+    info = dev.info()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup, then exactly K timed steps -----------------------------------------------------------------
+    if args.warmup > 0:
+        dev.run_passes(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = dev.run_passes(args.steps)   # K passes back to back on the library stream; returns after its sync
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tw = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = float(tw[0]), float(tw[1])
+
+    # ---- sanity of what was timed: mass conservation after the last pass --------------------------------
+    th = dev.get_theta()
+    mass = float((th * s["den"]).sum())
+    ok = bool(np.isfinite(th).all() and abs(mass - s["n_reads"]) <= 1e-8 * s["n_reads"])
+
+    out = None
+    if rank == 0:
+        per_pass_s = kernel_ms / 1e3 / args.steps
+        bytes_pass = info["bytes_per_pass"]
+        achieved = bytes_pass / per_pass_s / 1e9
+        out = {
+            "metric": "EM iterations/s", "value": world * args.steps / wall, "unit": "iter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d reads x %d transcripts, nnz %d (mean %.2f aln/read), read-level CSR, one sample per GPU"
+                       % (args.config, s["n_reads"], s["n_tx"], nnz, nnz / s["n_reads"]),
+                       "layout": "windowed" if info["layout"] == 2 else "csr", "parallelism": "1 sample per GPU x %d" % world},
+            "read_alignments_per_s": world * nnz * args.steps / wall,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_pass_windowed+k_update" if info["layout"] == 2 else "k_pass_csr+k_update",
+                         "algorithmic_bytes_per_pass": bytes_pass, "stored_bytes_per_pass": info["stored_bytes_per_pass"],
+                         "device_ms_per_pass": per_pass_s * 1e3},
+            "layout_stats": {k: info[k] for k in ("n_chunks", "n_slices", "padded_entries", "far_entries", "window")},
+            "setup_s": {"generate": round(t_gen, 2), "upload_and_layout": round(t_up, 2)},
+            "mass_conserved": ok,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(s, nnz)
+    dev.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(s, nnz):
+    """The CPU oracle's EM pass (oracle/em_oracle.c, OpenMP) on the same matrix, bounded to ~10-30 s."""
+    import numpy as np
+    import oracle as O
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
+    th = np.ones(s["n_tx"])
+    th, _ = m.em_step(th, s["den"], n_threads=cores)     # untimed warm pass
+    n, t0 = 0, time.perf_counter()
+    while True:
+        th, _ = m.em_step(th, s["den"], n_threads=cores)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 12.0 or n >= 50:
+            break
+    return {"value": n / dt, "unit": "iter/s", "cores": cores, "kind": "port",
+            "sample": "%d EM passes of the oracle's OpenMP EM over the same %d-read matrix (nnz %d)" % (n, s["n_reads"], nnz)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,786 @@
+// emsar_hip.hip -- MI355X (gfx950 / CDNA4) abundance-estimation core behind include/emsar_hip.h.
+//
+// Replaces run_MLE_threads() (/root/reference/src/emsar_main.c:446; MLE/Fp/lambdap,
+// emsar_functions.c:2946-3126) by an EM on the same segment Poisson likelihood:
+//     E-step  w_c = R_c / S_c ,  S_c = sum_t m_ct theta_t        (rows with E_c == 0 are outside F)
+//     M-step  theta_t <- theta_t * (sum_c m_ct w_c) / den_t ,    den_t = sum_c m_ct E_c
+// and compute_iEUMA / the TPM + iReadcount arithmetic of print_FPKMfinal (emsar_functions.c:3176-3232).
+//
+// One pass is HBM-bound integer streaming plus FP64 adds: ~2 flop per nonzero -- no MFMA.
+// Kernels:
+//   k_pass_windowed   the hot one: one workgroup per chunk, theta/acc windows in LDS, one lane per row,
+//                     column-major 64-row slices (256 contiguous bytes per wave load)
+//   k_pass_csr        generic fallback on the caller's CSR, one lane per row, FP64 atomics to L2/HBM
+//   k_update          theta' = theta*acc/den, clears acc, max-relative-change reduction
+//   k_sq_*            SQUAREM extrapolation / acceptance entirely on the device (no host round trip)
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/emsar_hip.h"
+#include "layout.hpp"
+
+namespace {
+
+using emsar::Chunk;
+constexpr int kPassThreads = 512;     // 8 waves per workgroup
+constexpr int kDefaultWindow = 4096;  // 2 x 32 KiB of LDS per workgroup -> 2 workgroups per CU
+constexpr int64_t kChunkEntries = 32768;
+
+// ------------------------------------------------------------------------------------------------
+// device scalars of one solve (lives in HBM, polled by the host every check_every cycles)
+// ------------------------------------------------------------------------------------------------
+struct Scal {
+    double ll[4];                 // sum_c R_c log S_c at the input of pass 0/1/2 of the cycle; [3] scratch
+    double sr2, sv2, pen1, penx;  // SQUAREM norms, sum theta*den of th1 and of the extrapolated point
+    double stepmax, s_used;
+    unsigned long long delta_bits;  // max_t |dtheta|/(theta+floor) as IEEE bits (non-negative -> integer max)
+    unsigned long long delta1_bits; // the same, frozen after the first (plain) pass of a SQUAREM cycle
+    int32_t accepted, rejected;
+    double sum_a, sum_b;          // generic reductions (normalise)
+};
+
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) {
+    // gfx950: global_atomic_add_f64 / ds_add_f64 (no CAS loop; compiled with -munsafe-fp-atomics)
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lds_add_f64(double *p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int THREADS>
+__device__ __forceinline__ double block_sum(double v, double *red /* THREADS/64 doubles of LDS */) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < THREADS / 64; i++) t += red[i];
+    return t;  // valid in thread 0
+}
+
+enum PassMode { MODE_EM = 0, MODE_EM_LL = 1, MODE_SCATTER = 2 };
+
+// ------------------------------------------------------------------------------------------------
+// k_pass_windowed: one EM pass (or a plain row-value scatter) over the WINDOWED layout.
+//   chunks[blockIdx.x]  -> slices [slice_begin, +n_slices), LDS window [lo, lo+width)
+//   lane l of a wave owns row slice*64+l; its j-th tid is ent[slice_off[slice] + j*64 + l]
+// HBM traffic per pass: ent once (4 B per stored slot), slice_off (8 B per 64 rows), optional row weights;
+// theta window loads and acc window flushes are O(n_tx + chunks*family) and stay in L2.
+// ------------------------------------------------------------------------------------------------
+template <int THREADS, bool WEIGHTED, int MODE>
+__global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restrict__ chunks,
+                                                           const uint64_t *__restrict__ slice_off,
+                                                           const int32_t *__restrict__ ent,
+                                                           const int32_t *__restrict__ wgt,   // sorted rows, padded
+                                                           const double *__restrict__ rowval, // MODE_SCATTER
+                                                           const double *__restrict__ theta,
+                                                           double *__restrict__ acc, double *__restrict__ ll_out,
+                                                           int window) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *th_w = lds;            // [window]
+    double *acc_w = lds + window;  // [window]
+    __shared__ double red[THREADS / 64];
+
+    const Chunk c = chunks[blockIdx.x];
+    const int lo = c.lo, width = c.width;
+    for (int i = threadIdx.x; i < width; i += THREADS) {
+        if (MODE != MODE_SCATTER) th_w[i] = theta[lo + i];
+        acc_w[i] = 0.0;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double ll = 0.0;
+    for (uint32_t s = wave; s < c.n_slices; s += THREADS / 64) {
+        const uint32_t gs = c.slice_begin + s;
+        const uint64_t off = slice_off[gs];
+        const int k = (int)((slice_off[gs + 1] - off) >> 6);
+        const int32_t *e = ent + off + lane;
+        double w;
+        if (MODE == MODE_SCATTER) {
+            w = rowval[(uint64_t)gs * 64 + lane];
+        } else {
+            double S = 0.0;
+            for (int j = 0; j < k; j++) {
+                int t = e[(size_t)j * 64];
+                if (t >= 0) {
+                    unsigned d = (unsigned)(t - lo);
+                    S += (d < (unsigned)width) ? th_w[d] : theta[t];
+                }
+            }
+            double r = WEIGHTED ? (double)wgt[(uint64_t)gs * 64 + lane] : 1.0;
+            bool live = (S > 0.0) && (r > 0.0);
+            w = live ? r / S : 0.0;
+            if (MODE == MODE_EM_LL && live) ll += r * log(S);
+        }
+        if (w != 0.0) {
+            for (int j = 0; j < k; j++) {
+                int t = e[(size_t)j * 64];
+                if (t < 0) break;  // padding is always at the tail of a row
+                unsigned d = (unsigned)(t - lo);
+                if (d < (unsigned)width) lds_add_f64(&acc_w[d], w);
+                else atomic_add_f64(&acc[t], w);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < width; i += THREADS) {
+        double v = acc_w[i];
+        if (v != 0.0) atomic_add_f64(&acc[lo + i], v);
+    }
+    if (MODE == MODE_EM_LL) {
+        double t = block_sum<THREADS>(ll, red);
+        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pass_csr: the same pass on the caller's CSR (any row order), one lane per row.
+// ------------------------------------------------------------------------------------------------
+template <typename PTR, bool WEIGHTED, int MODE>
+__global__ __launch_bounds__(256) void k_pass_csr(int64_t n_rows, const PTR *__restrict__ row_ptr,
+                                                  const int32_t *__restrict__ col, const int32_t *__restrict__ wgt,
+                                                  const double *__restrict__ rowval, const double *__restrict__ theta,
+                                                  double *__restrict__ acc, double *__restrict__ ll_out) {
+    __shared__ double red[4];
+    double ll = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) {
+        const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+        double w;
+        if (MODE == MODE_SCATTER) {
+            w = rowval[r];
+        } else {
+            double S = 0.0;
+            for (uint64_t k = b; k < e; k++) S += theta[col[k]];
+            double rw = WEIGHTED ? (double)wgt[r] : 1.0;
+            bool live = (S > 0.0) && (rw > 0.0);
+            w = live ? rw / S : 0.0;
+            if (MODE == MODE_EM_LL && live) ll += rw * log(S);
+        }
+        if (w != 0.0)
+            for (uint64_t k = b; k < e; k++) atomic_add_f64(&acc[col[k]], w);
+    }
+    if (MODE == MODE_EM_LL) {
+        double t = block_sum<256>(ll, red);
+        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// T-sized vector kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill_start(int n, const double *__restrict__ den, double *__restrict__ theta) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) theta[t] = den[t] > 0.0 ? 1.0 : 0.0;  // uniform interior start; tids outside F are defined 0
+}
+
+// theta_out = theta_in * acc / den ; acc <- 0 ; scal.delta = max |dtheta| / (theta_out + floor)
+__global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
+                                                const double *__restrict__ den, double *__restrict__ th_out,
+                                                double abs_floor, Scal *scal) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    double d = 0.0;
+    if (t < n) {
+        double a = acc[t], dn = den[t], x = th_in[t];
+        double y = dn > 0.0 ? x * a / dn : 0.0;
+        th_out[t] = y;
+        acc[t] = 0.0;
+        d = fabs(y - x) / (fabs(y) + abs_floor);
+        if (!(d == d)) d = __builtin_huge_val();  // NaN -> +inf so that the host sees it
+    }
+    for (int o = 32; o > 0; o >>= 1) d = fmax(d, __shfl_xor(d, o, 64));
+    if ((threadIdx.x & 63) == 0 && d > 0.0) atomicMax(&scal->delta_bits, (unsigned long long)__double_as_longlong(d));
+}
+
+__global__ void k_cycle_begin(Scal *s) {
+    s->ll[0] = s->ll[1] = s->ll[2] = s->ll[3] = 0.0;
+    s->sr2 = s->sv2 = s->pen1 = s->penx = 0.0;
+    s->delta_bits = 0ull;
+}
+__global__ void k_scal_init(Scal *s) {
+    s->stepmax = 1.0; s->s_used = 1.0; s->accepted = 0; s->rejected = 0; s->sum_a = s->sum_b = 0.0;
+}
+
+// after pass 1 and 2: r = th1-th0, v = (th2-th1)-r ; sr2=|r|^2, sv2=|v|^2, pen1 = sum th1*den
+__global__ __launch_bounds__(256) void k_sq_norms(int n, const double *__restrict__ th0, const double *__restrict__ th1,
+                                                  const double *__restrict__ th2, const double *__restrict__ den, Scal *scal) {
+    __shared__ double red[4];
+    int t = blockIdx.x * 256 + threadIdx.x;
+    double r2 = 0, v2 = 0, p1 = 0;
+    if (t < n) {
+        double r = th1[t] - th0[t], v = (th2[t] - th1[t]) - r;
+        r2 = r * r; v2 = v * v; p1 = th1[t] * den[t];
+    }
+    double a = block_sum<256>(r2, red); __syncthreads();
+    double b = block_sum<256>(v2, red); __syncthreads();
+    double c = block_sum<256>(p1, red);
+    if (threadIdx.x == 0) { atomic_add_f64(&scal->sr2, a); atomic_add_f64(&scal->sv2, b); atomic_add_f64(&scal->pen1, c); }
+}
+
+// thx = th0 + 2 s r + s^2 v  (Varadhan & Roland 2008, S3: s = |r|/|v| clamped to [1, stepmax]); components that
+// would leave the interior keep the plain EM value th2; s <= 1.01 -> thx = th2 (pass 3 is then one more EM step)
+__global__ __launch_bounds__(256) void k_sq_extrap(int n, const double *__restrict__ th0, const double *__restrict__ th1,
+                                                   const double *__restrict__ th2, const double *__restrict__ den,
+                                                   double *__restrict__ thx, Scal *scal) {
+    __shared__ double red[4];
+    double s = scal->sv2 > 0.0 ? sqrt(scal->sr2 / scal->sv2) : 1.0;
+    s = fmin(fmax(s, 1.0), scal->stepmax);
+    const bool extrap = s > 1.01;
+    int t = blockIdx.x * 256 + threadIdx.x;
+    double px = 0;
+    if (t < n) {
+        double x2 = th2[t], x = x2;
+        if (extrap) {
+            double r = th1[t] - th0[t], v = (x2 - th1[t]) - r;
+            double y = th0[t] + 2.0 * s * r + s * s * v;
+            x = (y > 0.0 && x2 > 0.0) ? y : x2;
+        }
+        thx[t] = x;
+        px = x * den[t];
+    }
+    double p = block_sum<256>(px, red);
+    if (threadIdx.x == 0) {
+        atomic_add_f64(&scal->penx, p);
+        if (blockIdx.x == 0) scal->s_used = extrap ? s : 1.0;
+    }
+}
+
+// after pass 3 (thn = EM(thx), ll[2] = sum R log S at thx): accept iff F(thx) >= F(th1), F = ll - sum theta*den
+__global__ __launch_bounds__(256) void k_sq_accept(int n, const double *__restrict__ thn, const double *__restrict__ th2,
+                                                   double *__restrict__ th0, Scal *scal) {
+    const double s = scal->s_used;
+    const bool extrap = s > 1.0;
+    const bool ok = !extrap || (scal->ll[2] - scal->penx >= scal->ll[1] - scal->pen1);
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) th0[t] = ok ? thn[t] : th2[t];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double sm = scal->stepmax;
+        if (!ok) { scal->rejected++; if (s >= sm) sm = fmax(1.0, sm / 4.0); }
+        else { scal->accepted++; }
+        if ((ok ? s : 1.0) >= sm) sm *= 4.0;
+        scal->stepmax = sm;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sum(int n, const double *__restrict__ x, double *out) {
+    __shared__ double red[4];
+    int t = blockIdx.x * 256 + threadIdx.x;
+    double s = block_sum<256>(t < n ? x[t] : 0.0, red);
+    if (threadIdx.x == 0) atomic_add_f64(out, s);
+}
+__global__ __launch_bounds__(256) void k_dot(int n, const double *__restrict__ x, const double *__restrict__ y, double *out) {
+    __shared__ double red[4];
+    int t = blockIdx.x * 256 + threadIdx.x;
+    double s = block_sum<256>(t < n ? x[t] * y[t] : 0.0, red);
+    if (threadIdx.x == 0) atomic_add_f64(out, s);
+}
+// print_FPKMfinal arithmetic (emsar_functions.c:3203-3207): TPM, iReadcount, Round_off
+__global__ void k_normalise(int n, const double *__restrict__ mean, const double *__restrict__ ieuma, double nreads_m,
+                            const double *total, double *__restrict__ tpm, double *__restrict__ ir, int32_t *__restrict__ iri) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double m = mean[t];
+    tpm[t] = m * 1E6 / *total;
+    double x = (ieuma[t] / 1E3) * m * nreads_m;
+    ir[t] = x;
+    int xi = (int)x;
+    iri[t] = (x - xi >= 0.5) ? xi + 1 : xi;
+}
+
+}  // namespace
+
+// ==================================================================================================
+// context
+// ==================================================================================================
+struct emsar_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    // structure
+    bool have_structure = false, have_sample = false;
+    int layout = EMSAR_LAYOUT_CSR;
+    int64_t n_rows = 0, nnz = 0;
+    int32_t n_tx = 0;
+    bool ptr64 = false;
+    // CSR layout (device)
+    void *d_row_ptr = nullptr;   // uint32 or uint64
+    int32_t *d_col = nullptr;
+    // WINDOWED layout
+    emsar::WindowedLayout L;     // host copy keeps perm / slice_off / chunks (ent freed after upload)
+    Chunk *d_chunks = nullptr;
+    uint64_t *d_slice_off = nullptr;
+    int32_t *d_ent = nullptr;
+    int64_t padded_rows = 0;
+    // sample
+    bool weighted = false;
+    int32_t *d_wgt = nullptr;    // row weights in layout order (0 = row outside F)
+    double *d_rowval = nullptr;  // scratch for scatter passes (den, iEUMA)
+    double loglik_const = 0.0;   // sum_c R_c log E_c over rows inside F
+    // vectors [n_tx]
+    double *d_den = nullptr, *d_acc = nullptr;
+    double *d_th[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // th0 th1 th2 thx thn
+    double *d_tmp[3] = {nullptr, nullptr, nullptr};
+    int32_t *d_itmp = nullptr;
+    Scal *d_scal = nullptr;
+    Scal *h_scal = nullptr;      // pinned
+    int64_t bytes_formula = 0, bytes_stored = 0;
+};
+
+namespace {
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+            return e_ == hipErrorOutOfMemory ? EMSAR_HIP_ERR_OOM : EMSAR_HIP_ERR_HIP;                   \
+        }                                                                                              \
+    } while (0)
+
+inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
+
+void free_structure(emsar_hip_ctx *ctx) {
+    hipFree(ctx->d_row_ptr); hipFree(ctx->d_col); hipFree(ctx->d_chunks); hipFree(ctx->d_slice_off); hipFree(ctx->d_ent);
+    ctx->d_row_ptr = nullptr; ctx->d_col = nullptr; ctx->d_chunks = nullptr; ctx->d_slice_off = nullptr; ctx->d_ent = nullptr;
+    hipFree(ctx->d_wgt); hipFree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
+    hipFree(ctx->d_den); hipFree(ctx->d_acc); ctx->d_den = nullptr; ctx->d_acc = nullptr;
+    for (auto &p : ctx->d_th) { hipFree(p); p = nullptr; }
+    for (auto &p : ctx->d_tmp) { hipFree(p); p = nullptr; }
+    hipFree(ctx->d_itmp); ctx->d_itmp = nullptr;
+    ctx->L = emsar::WindowedLayout();
+    ctx->have_structure = ctx->have_sample = false;
+}
+
+// one pass of the chosen layout.  mode: MODE_EM / MODE_EM_LL / MODE_SCATTER
+int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, double *ll_out) {
+    if (ctx->layout == EMSAR_LAYOUT_WINDOWED) {
+        const int W = ctx->L.window;
+        const size_t lds = (size_t)W * 2 * sizeof(double);
+        dim3 grid((unsigned)ctx->L.chunks.size()), block(kPassThreads);
+        if (grid.x == 0) return EMSAR_HIP_OK;
+#define LAUNCH_W(WT, MD)                                                                                          \
+    hipLaunchKernelGGL((k_pass_windowed<kPassThreads, WT, MD>), grid, block, lds, ctx->stream, ctx->d_chunks,      \
+                       ctx->d_slice_off, ctx->d_ent, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out, W)
+        if (mode == MODE_SCATTER) LAUNCH_W(false, MODE_SCATTER);
+        else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_W(true, MODE_EM_LL); else LAUNCH_W(true, MODE_EM); }
+        else { if (mode == MODE_EM_LL) LAUNCH_W(false, MODE_EM_LL); else LAUNCH_W(false, MODE_EM); }
+#undef LAUNCH_W
+    } else {
+        if (ctx->n_rows == 0) return EMSAR_HIP_OK;
+        int64_t blocks = (ctx->n_rows + 255) / 256;
+        dim3 grid((unsigned)std::min<int64_t>(blocks, 256 * 32)), block(256);
+#define LAUNCH_C(PT, WT, MD)                                                                                     \
+    hipLaunchKernelGGL((k_pass_csr<PT, WT, MD>), grid, block, 0, ctx->stream, ctx->n_rows, (const PT *)ctx->d_row_ptr, \
+                       ctx->d_col, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out)
+#define LAUNCH_CP(WT, MD) do { if (ctx->ptr64) LAUNCH_C(uint64_t, WT, MD); else LAUNCH_C(uint32_t, WT, MD); } while (0)
+        if (mode == MODE_SCATTER) LAUNCH_CP(false, MODE_SCATTER);
+        else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_CP(true, MODE_EM_LL); else LAUNCH_CP(true, MODE_EM); }
+        else { if (mode == MODE_EM_LL) LAUNCH_CP(false, MODE_EM_LL); else LAUNCH_CP(false, MODE_EM); }
+#undef LAUNCH_CP
+#undef LAUNCH_C
+    }
+    HIPCHK(hipGetLastError());
+    return EMSAR_HIP_OK;
+}
+
+// th_out = EM(th_in); ll slot receives sum R log S at th_in when want_ll
+int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_ll, int ll_slot, double abs_floor) {
+    int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot]);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_update, dim3(grid_for(ctx->n_tx, 256)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
+                       ctx->d_den, th_out, abs_floor, ctx->d_scal);
+    HIPCHK(hipGetLastError());
+    return EMSAR_HIP_OK;
+}
+
+// scatter a per-row value (original row order, host) to its columns: out[t] = sum_c m_ct val[c]
+int scatter_rows(emsar_hip_ctx *ctx, const double *val_host, double *d_out) {
+    std::vector<double> tmp;
+    const double *src = val_host;
+    size_t n = (size_t)ctx->n_rows;
+    if (ctx->layout == EMSAR_LAYOUT_WINDOWED) {
+        n = (size_t)ctx->padded_rows;
+        tmp.assign(n, 0.0);
+        for (int64_t i = 0; i < ctx->L.n_sorted_rows; i++) tmp[(size_t)i] = val_host[ctx->L.perm[(size_t)i]];
+        src = tmp.data();
+    }
+    if (n == 0) return EMSAR_HIP_OK;
+    if (!ctx->d_rowval) HIPCHK(hipMalloc(&ctx->d_rowval, std::max<size_t>(n, 1) * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->d_rowval, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_out, 0, (size_t)ctx->n_tx * sizeof(double), ctx->stream));
+    int rc = launch_pass(ctx, MODE_SCATTER, nullptr, d_out, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // tmp must outlive the copy
+    return EMSAR_HIP_OK;
+}
+
+}  // namespace
+
+// ==================================================================================================
+// C ABI
+// ==================================================================================================
+extern "C" {
+
+const char *emsar_hip_strerror(int status) {
+    switch (status) {
+        case EMSAR_HIP_OK: return "ok";
+        case EMSAR_HIP_ERR_ARG: return "invalid argument or malformed CSR";
+        case EMSAR_HIP_ERR_NO_DEVICE: return "no usable HIP device";
+        case EMSAR_HIP_ERR_OOM: return "out of memory";
+        case EMSAR_HIP_ERR_HIP: return "HIP runtime failure";
+        case EMSAR_HIP_ERR_STATE: return "wrong call order (upload_structure -> upload_sample -> solve)";
+        case EMSAR_HIP_ERR_NUMERIC: return "NaN/Inf in theta";
+        default: return "unknown status";
+    }
+}
+
+const char *emsar_hip_last_error(const emsar_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int emsar_hip_create(emsar_hip_ctx **out, int device_id) {
+    if (!out) return EMSAR_HIP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return EMSAR_HIP_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n) return EMSAR_HIP_ERR_NO_DEVICE;
+    emsar_hip_ctx *ctx = new (std::nothrow) emsar_hip_ctx();
+    if (!ctx) return EMSAR_HIP_ERR_OOM;
+    ctx->device = device_id;
+    auto fail = [&](int rc) { emsar_hip_destroy(ctx); return rc; };
+    if (hipSetDevice(device_id) != hipSuccess) return fail(EMSAR_HIP_ERR_NO_DEVICE);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
+    if (hipMalloc(&ctx->d_scal, sizeof(Scal)) != hipSuccess) return fail(EMSAR_HIP_ERR_OOM);
+    if (hipHostMalloc((void **)&ctx->h_scal, sizeof(Scal), hipHostMallocDefault) != hipSuccess) return fail(EMSAR_HIP_ERR_OOM);
+    // both pass kernels may need more than the default dynamic-LDS limit
+    *out = ctx;
+    return EMSAR_HIP_OK;
+}
+
+void emsar_hip_destroy(emsar_hip_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    free_structure(ctx);
+    hipFree(ctx->d_scal);
+    if (ctx->h_scal) hipHostFree(ctx->h_scal);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr,
+                               const int32_t *col_idx, int layout) {
+    if (!ctx) return EMSAR_HIP_ERR_ARG;
+    if (layout != EMSAR_LAYOUT_AUTO && layout != EMSAR_LAYOUT_CSR && layout != EMSAR_LAYOUT_WINDOWED) return EMSAR_HIP_ERR_ARG;
+    if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_structure(ctx);
+    ctx->n_rows = n_rows; ctx->n_tx = n_tx; ctx->nnz = (int64_t)row_ptr[n_rows];
+    ctx->ptr64 = (uint64_t)ctx->nnz >= (1ull << 32);
+    if (layout == EMSAR_LAYOUT_AUTO) layout = (n_rows < ((int64_t)1 << 32)) ? EMSAR_LAYOUT_WINDOWED : EMSAR_LAYOUT_CSR;
+    ctx->layout = layout;
+    const size_t T = (size_t)n_tx;
+    try {
+        if (layout == EMSAR_LAYOUT_WINDOWED) {
+            const char *wenv = getenv("EMSAR_HIP_WINDOW");
+            int window = wenv ? atoi(wenv) : kDefaultWindow;
+            if (window < emsar::kMinBlockTids || window > 8192) window = kDefaultWindow;
+            const char *cenv = getenv("EMSAR_HIP_CHUNK_ENTRIES");
+            int64_t chunk_entries = cenv ? atoll(cenv) : kChunkEntries;
+            if (chunk_entries < 1024) chunk_entries = kChunkEntries;
+            if (emsar::build_windowed(n_rows, n_tx, row_ptr, col_idx, window, chunk_entries, ctx->L) != 0) return EMSAR_HIP_ERR_ARG;
+            auto &L = ctx->L;
+            ctx->padded_rows = L.n_slices() * emsar::kSliceRows;
+            HIPCHK(hipMalloc(&ctx->d_chunks, std::max<size_t>(L.chunks.size(), 1) * sizeof(Chunk)));
+            HIPCHK(hipMalloc(&ctx->d_slice_off, L.slice_off.size() * sizeof(uint64_t)));
+            HIPCHK(hipMalloc(&ctx->d_ent, std::max<size_t>(L.ent.size(), 1) * sizeof(int32_t)));
+            HIPCHK(hipMemcpy(ctx->d_chunks, L.chunks.data(), L.chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(ctx->d_slice_off, L.slice_off.data(), L.slice_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(ctx->d_ent, L.ent.data(), L.ent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            ctx->bytes_stored = (int64_t)L.ent.size() * 4 + (int64_t)L.slice_off.size() * 8 + (int64_t)L.chunks.size() * 16;
+            std::vector<int32_t>().swap(L.ent);  // the device copy is the only one needed from here on
+            const size_t lds = (size_t)window * 2 * sizeof(double);
+#define SETLDS(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_windowed<kPassThreads, WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+            SETLDS(false, MODE_EM); SETLDS(false, MODE_EM_LL); SETLDS(true, MODE_EM); SETLDS(true, MODE_EM_LL); SETLDS(false, MODE_SCATTER);
+#undef SETLDS
+        } else {
+            if (ctx->ptr64) {
+                HIPCHK(hipMalloc(&ctx->d_row_ptr, ((size_t)n_rows + 1) * 8));
+                HIPCHK(hipMemcpy(ctx->d_row_ptr, row_ptr, ((size_t)n_rows + 1) * 8, hipMemcpyHostToDevice));
+            } else {
+                std::vector<uint32_t> rp((size_t)n_rows + 1);
+                for (int64_t r = 0; r <= n_rows; r++) rp[(size_t)r] = (uint32_t)row_ptr[r];
+                HIPCHK(hipMalloc(&ctx->d_row_ptr, rp.size() * 4));
+                HIPCHK(hipMemcpy(ctx->d_row_ptr, rp.data(), rp.size() * 4, hipMemcpyHostToDevice));
+            }
+            HIPCHK(hipMalloc(&ctx->d_col, std::max<size_t>((size_t)ctx->nnz, 1) * 4));
+            HIPCHK(hipMemcpy(ctx->d_col, col_idx, (size_t)ctx->nnz * 4, hipMemcpyHostToDevice));
+            ctx->bytes_stored = ctx->nnz * 4 + (n_rows + 1) * (ctx->ptr64 ? 8 : 4);
+        }
+    } catch (const std::bad_alloc &) {
+        free_structure(ctx);
+        return EMSAR_HIP_ERR_OOM;
+    }
+    HIPCHK(hipMalloc(&ctx->d_den, T * 8));
+    HIPCHK(hipMalloc(&ctx->d_acc, T * 8));
+    for (auto &p : ctx->d_th) HIPCHK(hipMalloc(&p, T * 8));
+    for (auto &p : ctx->d_tmp) HIPCHK(hipMalloc(&p, T * 8));
+    HIPCHK(hipMalloc(&ctx->d_itmp, T * 4));
+    HIPCHK(hipMemset(ctx->d_acc, 0, T * 8));
+    ctx->have_structure = true;
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const double *row_E, const double *den) {
+    if (!ctx) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_structure) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int64_t n_rows = ctx->n_rows;
+    // a row counts w = R (or 1) when it is inside the likelihood (E != 0), else 0
+    ctx->weighted = (row_weight != nullptr) || (row_E != nullptr);
+    ctx->loglik_const = 0.0;
+    hipFree(ctx->d_wgt); ctx->d_wgt = nullptr;
+    if (ctx->weighted) {
+        for (int64_t r = 0; r < n_rows; r++) {
+            if (row_weight && row_weight[r] < 0) return EMSAR_HIP_ERR_ARG;
+            if (row_E && !(row_E[r] >= 0.0)) return EMSAR_HIP_ERR_ARG;  // negative or NaN
+        }
+        const bool win = ctx->layout == EMSAR_LAYOUT_WINDOWED;
+        size_t n = win ? (size_t)ctx->padded_rows : (size_t)n_rows;
+        std::vector<int32_t> w(std::max<size_t>(n, 1), 0);
+        int64_t cnt = win ? ctx->L.n_sorted_rows : n_rows;
+        for (int64_t i = 0; i < cnt; i++) {
+            int64_t r = win ? (int64_t)ctx->L.perm[(size_t)i] : i;
+            int32_t x = row_weight ? row_weight[r] : 1;
+            if (row_E && row_E[r] == 0.0) x = 0;
+            w[(size_t)i] = x;
+            if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[r]);
+        }
+        HIPCHK(hipMalloc(&ctx->d_wgt, w.size() * 4));
+        HIPCHK(hipMemcpy(ctx->d_wgt, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (den) {
+        for (int32_t t = 0; t < ctx->n_tx; t++) if (!(den[t] >= 0.0)) return EMSAR_HIP_ERR_ARG;
+        HIPCHK(hipMemcpy(ctx->d_den, den, (size_t)ctx->n_tx * 8, hipMemcpyHostToDevice));
+    } else {
+        std::vector<double> ones;
+        const double *e = row_E;
+        if (!e) { ones.assign((size_t)std::max<int64_t>(n_rows, 1), 1.0); e = ones.data(); }
+        int rc = scatter_rows(ctx, e, ctx->d_den);
+        if (rc) return rc;
+    }
+    ctx->bytes_formula = 4 * ctx->nnz + (ctx->ptr64 ? 8 : 4) * (ctx->n_rows + 1) + (row_weight ? 4 : 0) * ctx->n_rows + 32 * (int64_t)ctx->n_tx;
+    ctx->have_sample = true;
+    return emsar_hip_reset_theta(ctx);
+}
+
+int emsar_hip_reset_theta(emsar_hip_ctx *ctx) {
+    if (!ctx) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_fill_start, dim3(grid_for(ctx->n_tx, 256)), dim3(256), 0, ctx->stream, ctx->n_tx, ctx->d_den, ctx->d_th[0]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_set_theta(emsar_hip_ctx *ctx, const double *theta) {
+    if (!ctx || !theta) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(ctx->d_th[0], theta, (size_t)ctx->n_tx * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_get_theta(emsar_hip_ctx *ctx, double *theta) {
+    if (!ctx || !theta) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(theta, ctx->d_th[0], (size_t)ctx->n_tx * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_run_passes(emsar_hip_ctx *ctx, int32_t n_passes, float *elapsed_ms, double *last_ll) {
+    if (!ctx || n_passes < 0) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    int cur = 0;  // th[cur] holds the current point, th[cur^1] receives the next
+    for (int i = 0; i < n_passes; i++) {
+        bool ll = last_ll && i == n_passes - 1;
+        int rc = em_pass(ctx, ctx->d_th[cur], ctx->d_th[cur ^ 1], ll, 0, 1e-6);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (cur == 1) HIPCHK(hipMemcpyAsync(ctx->d_th[0], ctx->d_th[1], (size_t)ctx->n_tx * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (elapsed_ms) HIPCHK(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    if (last_ll) *last_ll = ctx->h_scal->ll[0];
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_out, emsar_em_stats *stats) {
+    if (!ctx || !fpkm_out) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
+    emsar_em_params p = pp ? *pp : emsar_em_params{0, 1, 0, 0, 0, 0};
+    if (p.max_iter <= 0) p.max_iter = 100000;
+    if (p.tol <= 0) p.tol = 1e-10;
+    if (p.abs_floor <= 0) p.abs_floor = 1e-6;
+    if (p.check_every <= 0) p.check_every = 8;
+    HIPCHK(hipSetDevice(ctx->device));
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = emsar_hip_reset_theta(ctx);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    const int n = ctx->n_tx, g = grid_for(n, 256);
+    double **th = ctx->d_th;  // 0:th0 1:th1 2:th2 3:thx 4:thn
+    int iters = 0, converged = 0, cycles = 0;
+    double delta = INFINITY;
+    while (iters < p.max_iter) {
+        hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
+        if (!p.accel) {
+            if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor))) return rc;
+            std::swap(th[0], th[1]);
+            iters += 1;
+        } else {
+            // delta is measured on the first (plain) step of the cycle only: pass 2/3 must not overwrite it
+            if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor))) return rc;
+            HIPCHK(hipMemcpyAsync(&ctx->d_scal->delta1_bits, &ctx->d_scal->delta_bits, 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if ((rc = em_pass(ctx, th[1], th[2], true, 1, p.abs_floor))) return rc;
+            hipLaunchKernelGGL(k_sq_norms, dim3(g), dim3(256), 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, ctx->d_scal);
+            hipLaunchKernelGGL(k_sq_extrap, dim3(g), dim3(256), 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, th[3], ctx->d_scal);
+            if ((rc = em_pass(ctx, th[3], th[4], true, 2, p.abs_floor))) return rc;
+            hipLaunchKernelGGL(k_sq_accept, dim3(g), dim3(256), 0, ctx->stream, n, th[4], th[2], th[0], ctx->d_scal);
+            HIPCHK(hipGetLastError());
+            iters += 3;
+        }
+        cycles++;
+        if (cycles % p.check_every == 0 || iters >= p.max_iter) {
+            HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            unsigned long long bits = p.accel ? ctx->h_scal->delta1_bits : ctx->h_scal->delta_bits;
+            memcpy(&delta, &bits, 8);
+            if (!std::isfinite(delta)) { ctx->err = "non-finite theta"; return EMSAR_HIP_ERR_NUMERIC; }
+            if (delta < p.tol) { converged = 1; break; }
+        }
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    // F at the returned point: one likelihood-only pass (not counted in iters)
+    hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
+    if ((rc = launch_pass(ctx, MODE_EM_LL, th[0], ctx->d_acc, &ctx->d_scal->ll[0]))) return rc;
+    HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)n * 8, ctx->stream));
+    hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, ctx->stream, n, th[0], ctx->d_den, &ctx->d_scal->ll[3]);
+    HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(fpkm_out, th[0], (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int32_t t = 0; t < n; t++)
+        if (!std::isfinite(fpkm_out[t])) { ctx->err = "non-finite theta"; return EMSAR_HIP_ERR_NUMERIC; }
+    if (stats) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        stats->iters = iters;
+        stats->converged = converged;
+        stats->final_delta = delta;
+        stats->loglik = ctx->h_scal->ll[0] + ctx->loglik_const - ctx->h_scal->ll[3];
+        stats->kernel_ms = ms;
+        stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        stats->bytes_per_pass = ctx->bytes_formula;
+        stats->stored_bytes_per_pass = ctx->bytes_stored + (ctx->weighted ? 4 * (ctx->layout == EMSAR_LAYOUT_WINDOWED ? ctx->padded_rows : ctx->n_rows) : 0) + 32 * (int64_t)n;
+    }
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_ieuma(emsar_hip_ctx *ctx, const double *row_L, double *ieuma_out) {
+    if (!ctx || !row_L || !ieuma_out) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_structure) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = scatter_rows(ctx, row_L, ctx->d_tmp[0]);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(ieuma_out, ctx->d_tmp[0], (size_t)ctx->n_tx * 8, hipMemcpyDeviceToHost));
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_normalise(emsar_hip_ctx *ctx, const double *mean_fpkm, const double *ieuma, int64_t total_read_count,
+                        double *tpm_out, double *ir_out, int32_t *iri_out) {
+    if (!ctx || !mean_fpkm || !ieuma || !tpm_out || !ir_out || !iri_out) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_structure) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->n_tx, g = grid_for(n, 256);
+    const size_t B = (size_t)n * 8;
+    HIPCHK(hipMemcpyAsync(ctx->d_tmp[0], mean_fpkm, B, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_tmp[1], ieuma, B, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(&ctx->d_scal->sum_b, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_sum, dim3(g), dim3(256), 0, ctx->stream, n, ctx->d_tmp[0], &ctx->d_scal->sum_b);
+    // tmp[2] <- tpm, acc <- iReadcount (acc is zero between passes and is cleared again below)
+    hipLaunchKernelGGL(k_normalise, dim3(g), dim3(256), 0, ctx->stream, n, ctx->d_tmp[0], ctx->d_tmp[1],
+                       (double)total_read_count / 1E6, &ctx->d_scal->sum_b, ctx->d_tmp[2], ctx->d_acc, ctx->d_itmp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(tpm_out, ctx->d_tmp[2], B, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ir_out, ctx->d_acc, B, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(iri_out, ctx->d_itmp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_acc, 0, B, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *o) {
+    if (!ctx || !o) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_structure) return EMSAR_HIP_ERR_STATE;
+    memset(o, 0, sizeof(*o));
+    o->n_rows = ctx->n_rows; o->nnz = ctx->nnz; o->n_tx = ctx->n_tx; o->layout = ctx->layout; o->device_id = ctx->device;
+    if (ctx->layout == EMSAR_LAYOUT_WINDOWED) {
+        o->n_chunks = (int64_t)ctx->L.chunks.size();
+        o->n_slices = ctx->L.n_slices();
+        o->padded_entries = (int64_t)ctx->L.slice_off.back();
+        o->far_entries = ctx->L.far_entries;
+        o->window = ctx->L.window;
+    }
+    o->bytes_per_pass = ctx->bytes_formula;
+    o->stored_bytes_per_pass = ctx->bytes_stored + (ctx->weighted ? 4 * (ctx->layout == EMSAR_LAYOUT_WINDOWED ? ctx->padded_rows : ctx->n_rows) : 0) + 32 * (int64_t)ctx->n_tx;
+    return EMSAR_HIP_OK;
+}
+
+// Host-only self check of the WINDOWED layout builder (no HIP call: usable on a machine without a GPU).
+// Builds the layout for the given CSR, decodes it again and compares; fills *info_out (may be NULL).
+int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
+                               int32_t window, int64_t chunk_entries, emsar_hip_info *info_out) {
+    if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
+    emsar::WindowedLayout L;
+    if (window <= 0) window = kDefaultWindow;
+    if (chunk_entries <= 0) chunk_entries = kChunkEntries;
+    if (emsar::build_windowed(n_rows, n_tx, row_ptr, col_idx, window, chunk_entries, L) != 0) return EMSAR_HIP_ERR_ARG;
+    int rc = emsar::check_windowed(L, row_ptr, col_idx);
+    if (info_out) {
+        memset(info_out, 0, sizeof(*info_out));
+        info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx; info_out->layout = EMSAR_LAYOUT_WINDOWED;
+        info_out->n_chunks = (int64_t)L.chunks.size(); info_out->n_slices = L.n_slices();
+        info_out->padded_entries = (int64_t)L.slice_off.back(); info_out->far_entries = L.far_entries; info_out->window = window;
+    }
+    return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+"""Seeded synthetic read->transcript compatibility matrices of the BASELINE.json shapes.
+
+A read picks its transcript with probability proportional to theta*_t * len_t (theta* ~ LogNormal(0,2), 30 %
+exact zeros) and is compatible with a window of k neighbouring transcript ids around it (isoforms of one gene
+are neighbours in a cDNA FASTA, hence in EMSAR's tid space); a small fraction also hits one transcript
+anywhere (cross-family paralog).  k follows the per-config alignment-count law.  Rows are emitted in random
+read order, exactly like an unsorted alignment file: any locality the kernels exploit has to be created by the
+library at upload time.
+
+The generator is ours (the reference's readgenerator.c is not built and works at sequence level); it emits the
+CSR directly.  den_t = len_t/1e3 * N/1e6 plays the role of sum_c m_ct E_c (effective length in kb x million reads).
+"""
+import numpy as np
+
+CONFIGS = {
+    # name: (n_tx, n_reads, k law, cross-family fraction, seed)
+    "cfg2": dict(n_tx=80_000, n_reads=5_000_000, law="poisson2", xfam=0.0, seed=2),
+    "cfg3": dict(n_tx=200_000, n_reads=50_000_000, law="human", xfam=0.02, seed=3),
+    "cfg4": dict(n_tx=200_000, n_reads=20_000_000, law="human", xfam=0.02, seed=40),
+    "cfg5": dict(n_tx=250_000, n_reads=200_000_000, law="repeats", xfam=0.02, seed=5),
+}
+
+
+def _draw_k(rng, n, law):
+    if law == "poisson2":      # 1 + Poisson(2) truncated to [1,100]: mean 3
+        k = 1 + rng.poisson(2.0, n)
+    elif law == "human":       # 60 % unique, rest 1 + geometric (mean 10): overall mean ~5, cap 100 (-k 100)
+        k = np.ones(n, dtype=np.int64)
+        multi = rng.random(n) >= 0.6
+        k[multi] = 1 + rng.geometric(0.1, int(multi.sum()))
+    elif law == "repeats":     # heavy repeats: 10 % of reads hit 50-100 members, rest 1 + geometric(mean 13): mean ~20
+        k = 1 + rng.geometric(1.0 / 13.0, n)
+        big = rng.random(n) < 0.1
+        k[big] = rng.integers(50, 101, int(big.sum()))
+    else:
+        raise ValueError(law)
+    return np.clip(k, 1, 100).astype(np.int32)
+
+
+def make_abundance(n_tx, seed):
+    rng = np.random.default_rng(seed)
+    theta = rng.lognormal(0.0, 2.0, n_tx)
+    theta[rng.random(n_tx) < 0.3] = 0.0
+    length = np.clip(rng.lognormal(np.log(1800.0), 0.6, n_tx), 200, 20000)
+    return theta, length
+
+
+def make_matrix(n_tx, n_reads, law="human", xfam=0.02, seed=1, block=5_000_000):
+    """Returns dict(row_ptr u64[n_reads+1], col_idx i32[nnz], den f64[n_tx], theta_true, n_tx, n_reads)."""
+    theta, length = make_abundance(n_tx, seed)
+    p = theta * length
+    cdf = np.cumsum(p)
+    cdf /= cdf[-1]
+    rng = np.random.default_rng(seed + 1000)
+    lens = np.empty(n_reads, dtype=np.int32)
+    cols = []
+    for b0 in range(0, n_reads, block):
+        n = min(block, n_reads - b0)
+        t0 = np.searchsorted(cdf, rng.random(n), side="right").astype(np.int32)
+        np.minimum(t0, n_tx - 1, out=t0)
+        k = np.minimum(_draw_k(rng, n, law), n_tx)
+        # window of k consecutive tids that contains t0
+        start = t0 - (rng.random(n) * k).astype(np.int32)
+        np.clip(start, 0, n_tx - k, out=start)
+        x = (rng.random(n) < xfam) if xfam > 0 else np.zeros(n, dtype=bool)
+        kk = k + x.astype(np.int32)
+        lens[b0:b0 + n] = kk
+        rp = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(kk, out=rp[1:])
+        nnz = int(rp[-1])
+        row = np.repeat(np.arange(n, dtype=np.int32), kk)
+        j = (np.arange(nnz, dtype=np.int64) - rp[row]).astype(np.int32)
+        c = start[row] + j
+        # the extra cross-family hit sits in the last slot of its row
+        last = rp[1:][x] - 1
+        c[last] = rng.integers(0, n_tx, int(x.sum()), dtype=np.int32)
+        cols.append(c.astype(np.int32))
+        del row, j, c, rp
+    col_idx = np.concatenate(cols) if len(cols) > 1 else cols[0]
+    del cols
+    row_ptr = np.zeros(n_reads + 1, dtype=np.uint64)
+    np.cumsum(lens, out=row_ptr[1:], dtype=np.uint64)
+    den = length / 1e3 * (n_reads / 1e6)
+    return {"n_tx": n_tx, "n_reads": n_reads, "row_ptr": row_ptr, "col_idx": col_idx, "den": den,
+            "theta_true": theta}
+
+
+def make_config(name, scale=1.0):
+    """BASELINE.json config by name; scale < 1 shrinks reads AND transcripts proportionally (parity tests)."""
+    c = dict(CONFIGS[name])
+    c["n_reads"] = max(1000, int(c["n_reads"] * scale))
+    c["n_tx"] = max(500, int(c["n_tx"] * scale))
+    return make_matrix(**c)
+
+
+def collapse(row_ptr, col_idx):
+    """Read-level -> segment-level: unique rows (as tid multisets in the given order) + counts.
+    What the reference's update_ReadCounts does read by read (emsar_functions.c:838-943).  Small inputs only
+    (python dict); used by tests to check that the collapsed and the read-level solve agree."""
+    seen, order, counts = {}, [], []
+    rp = row_ptr.astype(np.int64)
+    for r in range(len(rp) - 1):
+        key = tuple(sorted(col_idx[rp[r]:rp[r + 1]].tolist()))
+        i = seen.get(key)
+        if i is None:
+            seen[key] = len(order)
+            order.append(key)
+            counts.append(1)
+        else:
+            counts[i] += 1
+    new_rp = np.zeros(len(order) + 1, dtype=np.uint64)
+    new_rp[1:] = np.cumsum([len(k) for k in order])
+    new_col = np.fromiter((t for k in order for t in k), dtype=np.int32, count=int(new_rp[-1]))
+    return new_rp, new_col, np.array(counts, dtype=np.int32)

@@ -1,0 +1,140 @@
+/* emsar_hip.h -- C ABI of libemsar_hip.so, the MI355X (gfx950) abundance-estimation core.
+ *
+ * Drop-in boundary: the reference has no plugin API; the seam is the call
+ *     run_MLE_threads();                                   /root/reference/src/emsar_main.c:446
+ * bracketed by construct_EUMAps() (emsar_main.c:436) and construct_FPKMfinal(round) (emsar_main.c:448),
+ * which reads the globals CT, ReadCount, EUMAps, SC, ST (emsar.h:129-170) and writes FPKM[0..max_tid].
+ * This library replaces that call, plus compute_iEUMA (emsar_functions.c:3218-3232) and the numeric part
+ * of print_FPKMfinal (emsar_functions.c:3176-3207).  Plain C types only: a C host (ours: emsar_amd/csrc/host,
+ * or the reference's emsar_main.c with the stub shown in INTEGRATION.md) links it directly.
+ *
+ * Conventions: every entry point returns 0 on success or a negative emsar_hip_status; nothing exits the
+ * process (the reference exit(1)s, e.g. emsar_functions.c:3133).  The caller keeps ownership of all host
+ * arrays; they may be freed as soon as the call returns.  One context per GPU; contexts share nothing, so
+ * the -M multi-sample path (emsar_main.c:380-488) runs one host thread or process per device.
+ *
+ * Matrix convention: row c = one segment (a distinct tid multiset, CT[c], emsar.h:129) or one read;
+ * columns = transcript ids; a tid may repeat inside a row and then counts twice, exactly as lambdap and
+ * compute_iEUMA count it (emsar_functions.c:2969-2973, 3226-3228).
+ */
+#ifndef EMSAR_HIP_H
+#define EMSAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct emsar_hip_ctx emsar_hip_ctx; /* opaque; one per GPU */
+
+typedef enum {
+    EMSAR_HIP_OK = 0,
+    EMSAR_HIP_ERR_ARG = -1,        /* NULL / out-of-range argument, malformed CSR (tid outside [0,n_tx)) */
+    EMSAR_HIP_ERR_NO_DEVICE = -2,  /* no HIP device, or device_id out of range */
+    EMSAR_HIP_ERR_OOM = -3,        /* host or device allocation failed */
+    EMSAR_HIP_ERR_HIP = -4,        /* a HIP runtime call or kernel failed (see emsar_hip_last_error) */
+    EMSAR_HIP_ERR_STATE = -5,      /* call order: upload_structure -> upload_sample -> solve */
+    EMSAR_HIP_ERR_NUMERIC = -6     /* NaN/Inf met in theta (infeasible input such as R>0 on an all-zero row) */
+} emsar_hip_status;
+
+/* How the structure is laid out in HBM (DESIGN.md "Data layout"). */
+typedef enum {
+    EMSAR_LAYOUT_AUTO = 0,   /* WINDOWED when it applies, else CSR */
+    EMSAR_LAYOUT_CSR = 1,    /* rows as given; lane-per-row walk, FP64 atomics straight to HBM/L2 */
+    EMSAR_LAYOUT_WINDOWED = 2 /* rows bucketed by smallest tid and length into 64-row column-major slices;
+                                 theta / accumulator windows staged in LDS */
+} emsar_hip_layout;
+
+/* Replaces the solver knobs -e/-r/-i/-l/-n of the reference (emsar_main.c:86-91): the pattern search's
+ * step/F epsilons have no meaning for an EM; they map to tol / max_iter. */
+typedef struct {
+    int32_t max_iter;     /* cap on EM passes (one pass = one sweep over the matrix); <=0 -> 100000 */
+    int32_t accel;        /* 0 plain EM; 1 SQUAREM (3 passes per cycle, likelihood-safeguarded) */
+    double  tol;          /* stop when max_t |dtheta_t| / (theta_t + abs_floor) < tol; <=0 -> 1e-10 */
+    double  abs_floor;    /* <=0 -> 1e-6, the %lf print quantum of the reference's .fpkm */
+    int32_t check_every;  /* host looks at the device convergence word every this many cycles; <=0 -> 8 */
+    int32_t reserved;
+} emsar_em_params;
+
+typedef struct {
+    int32_t iters;            /* EM passes executed */
+    int32_t converged;        /* 1 if tol was met */
+    double  final_delta;      /* last max_t |dtheta|/(theta+abs_floor) */
+    double  loglik;           /* F(theta) = sum_c R_c log(E_c S_c) - E_c S_c, rows with E_c != 0 (Fp, emsar_functions.c:2946) */
+    double  solve_ms;         /* wall time of the solve, upload excluded */
+    double  kernel_ms;        /* device time of all EM passes (HIP events on the context's stream) */
+    int64_t bytes_per_pass;   /* algorithmic bytes of one pass, SURVEY.md 8d: 4 nnz + P (rows+1) + W rows + 32 T */
+    int64_t stored_bytes_per_pass; /* bytes the chosen layout actually streams per pass */
+} emsar_em_stats;
+
+/* ---- lifetime ---------------------------------------------------------------------------------- */
+int  emsar_hip_create(emsar_hip_ctx **out, int device_id);
+void emsar_hip_destroy(emsar_hip_ctx *ctx);
+const char *emsar_hip_strerror(int status);
+const char *emsar_hip_last_error(const emsar_hip_ctx *ctx); /* text of the last HIP failure, "" if none */
+
+/* ---- inputs ------------------------------------------------------------------------------------
+ * upload_structure: the incidence CT (emsar.h:129, built by scan_rshbucket emsar_functions.c:2135-2192) as
+ * CSR; called once per rsh.  The library validates 0 <= col_idx < n_tx and monotone row_ptr on the host
+ * before anything reaches a kernel. */
+int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
+                               const uint64_t *row_ptr /* n_rows+1 */, const int32_t *col_idx /* nnz */,
+                               int layout /* emsar_hip_layout */);
+
+/* upload_sample: per-sample vectors; called once per alignment file (the body of the loop emsar_main.c:380).
+ *   row_weight = ReadCount[c] (emsar.h:142), NULL = every row counts 1 (read-level matrix)
+ *   row_E      = EUMAps[c]   (construct_EUMAps, emsar_functions.c:3148-3154), NULL = 1.0 everywhere;
+ *                rows with E == 0 are outside the likelihood (emsar_functions.c:2952)
+ *   den        = optional precomputed sum_c m_ct E_c per transcript; NULL = computed on the device */
+int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const double *row_E,
+                            const double *den);
+
+/* ---- the hot path: replaces run_MLE_threads() (emsar_main.c:446) --------------------------------
+ * Starts from the uniform interior point (theta = 1 where den > 0, else 0), runs EM to tol and copies
+ * theta (= FPKM[], emsar.h:160) to fpkm_out[n_tx].  stats may be NULL. */
+int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *p, double *fpkm_out, emsar_em_stats *stats);
+
+/* Lower-level stepping, used by bench.py and the parity tests:
+ *   reset        theta <- uniform start
+ *   set/get      move theta between host and device
+ *   run_passes   n plain EM passes back to back on the context's stream, no host synchronisation inside;
+ *                *elapsed_ms (may be NULL) = device time between HIP events recorded on that stream around
+ *                the n passes, *last_loglik_terms (may be NULL) = sum_c R_c log S_c at the input of the last pass */
+int emsar_hip_reset_theta(emsar_hip_ctx *ctx);
+int emsar_hip_set_theta(emsar_hip_ctx *ctx, const double *theta /* n_tx */);
+int emsar_hip_get_theta(emsar_hip_ctx *ctx, double *theta /* n_tx */);
+int emsar_hip_run_passes(emsar_hip_ctx *ctx, int32_t n_passes, float *elapsed_ms, double *last_loglik_terms);
+
+/* ---- post-processing: compute_iEUMA + print_FPKMfinal arithmetic --------------------------------
+ * ieuma[t] = sum over ALL rows of m_ct * row_L[c]  (adjEUMA, emsar_functions.c:3224-3231). */
+int emsar_hip_ieuma(emsar_hip_ctx *ctx, const double *row_L /* n_rows */, double *ieuma_out /* n_tx */);
+/* From the mean FPKM: TPM = mean*1e6/sum(mean); iReadcount = ieuma/1e3 * mean * N/1e6  (emsar_functions.c:3203,3207). */
+int emsar_hip_normalise(emsar_hip_ctx *ctx, const double *mean_fpkm, const double *ieuma, int64_t total_read_count,
+                        double *tpm_out, double *ireadcount_out, int32_t *ireadcount_int_out);
+
+/* ---- introspection ------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t n_rows, nnz;
+    int32_t n_tx;
+    int32_t layout;            /* layout in use */
+    int64_t n_chunks;          /* WINDOWED: workgroup-sized work items */
+    int64_t n_slices;          /* WINDOWED: 64-row slices */
+    int64_t padded_entries;    /* WINDOWED: stored column slots incl. padding */
+    int64_t far_entries;       /* WINDOWED: entries outside their chunk's LDS window (global atomics) */
+    int32_t window;            /* WINDOWED: transcripts per LDS window */
+    int32_t device_id;
+    int64_t bytes_per_pass;        /* SURVEY.md 8d formula */
+    int64_t stored_bytes_per_pass; /* what the layout streams */
+} emsar_hip_info;
+int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *out);
+
+/* Host-only diagnostic (no HIP call, works without a GPU): build the WINDOWED layout for a CSR, decode it
+ * again and check that it stores exactly the input rows.  window / chunk_entries <= 0 select the defaults. */
+int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
+                               int32_t window, int64_t chunk_entries, emsar_hip_info *info_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMSAR_HIP_H */

@@ -1,0 +1,98 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/emsar_hip.h declares, refuses to run without a device, and its host-side layout builder stores
+exactly the rows it was given.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import emsar_amd
+from emsar_amd import hip as H
+from emsar_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from emsar_amd import _build
+    _build.build_hip()
+    return emsar_amd.load_library()
+
+
+def test_header_symbols_are_exported(lib):
+    text = open(os.path.join(ROOT, "include", "emsar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(emsar_hip_[a-z_]+)\s*\(", text)))
+    assert declared == sorted(H.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_sizes_match_header(lib):
+    # plain C layout, no padding surprises between the header and the ctypes mirror
+    assert C.sizeof(H.EmParams) == 4 + 4 + 8 + 8 + 4 + 4
+    assert C.sizeof(H.EmStats) == 4 + 4 + 8 * 4 + 8 * 2
+    assert C.sizeof(H.Info) == 8 * 2 + 4 * 2 + 8 * 4 + 4 * 2 + 8 * 2
+
+
+def test_strerror(lib):
+    assert lib.emsar_hip_strerror(0) == b"ok"
+    for s in range(-6, 0):
+        assert lib.emsar_hip_strerror(s) not in (b"ok", b"unknown status")
+
+
+def test_no_silent_fallback_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(emsar_amd.EmsarHipError) as e:
+        emsar_amd.EmsarHip(0)
+    assert e.value.status == -2      # EMSAR_HIP_ERR_NO_DEVICE: the product path fails loudly, no CPU path
+
+
+def test_null_and_malformed_arguments(lib):
+    assert lib.emsar_hip_create(None, 0) == -1
+    assert lib.emsar_hip_upload_structure(None, 0, 1, None, None, 0) == -1
+    rp = np.array([0, 2, 1], dtype=np.uint64)           # not monotone
+    ci = np.array([0, 1], dtype=np.int32)
+    with pytest.raises(emsar_amd.EmsarHipError):
+        emsar_amd.layout_selfcheck(4, rp, ci)
+    rp = np.array([0, 2], dtype=np.uint64)
+    for bad in ([0, 4], [-1, 0]):                        # tid outside [0, n_tx)
+        with pytest.raises(emsar_amd.EmsarHipError):
+            emsar_amd.layout_selfcheck(4, rp, np.array(bad, dtype=np.int32))
+
+
+@pytest.mark.parametrize("window,chunk", [(0, 0), (256, 1024), (1024, 4096)])
+def test_layout_roundtrip_synthetic(lib, window, chunk):
+    m = synth.make_matrix(n_tx=6000, n_reads=40000, law="human", xfam=0.05, seed=9)
+    info = emsar_amd.layout_selfcheck(m["n_tx"], m["row_ptr"], m["col_idx"], window, chunk)
+    nnz = len(m["col_idx"])
+    assert info["nnz"] == nnz and info["padded_entries"] >= nnz
+    if window == 0:
+        assert info["padded_entries"] <= 1.35 * nnz       # length-sorted slices keep padding small
+    assert info["n_slices"] == (m["n_reads"] + 63) // 64
+    if window == 256:
+        assert info["far_entries"] > 0                    # cross-family hits fall outside a small window
+
+
+def test_layout_roundtrip_edge_cases(lib):
+    # empty matrix, empty rows, one row, one very long row, duplicate tids inside a row
+    emsar_amd.layout_selfcheck(5, np.array([0], dtype=np.uint64), np.array([], dtype=np.int32))
+    emsar_amd.layout_selfcheck(5, np.array([0, 0, 0], dtype=np.uint64), np.array([], dtype=np.int32))
+    emsar_amd.layout_selfcheck(5, np.array([0, 1], dtype=np.uint64), np.array([4], dtype=np.int32))
+    emsar_amd.layout_selfcheck(5, np.array([0, 0, 3, 3, 4], dtype=np.uint64), np.array([2, 4, 4, 0], dtype=np.int32))
+    rng = np.random.default_rng(0)
+    long_row = rng.integers(0, 3000, 700).astype(np.int32)
+    rp = np.array([0, 700, 701], dtype=np.uint64)
+    info = emsar_amd.layout_selfcheck(3000, rp, np.append(long_row, 5).astype(np.int32))
+    assert info["n_slices"] == 1 and info["padded_entries"] == 64 * 700
+
+
+def test_layout_roundtrip_golden(lib, golden):
+    m = golden.model
+    info = emsar_amd.layout_selfcheck(m.n_tx, m.row_ptr, m.col_idx, 256, 2048)
+    assert info["nnz"] == len(m.col_idx)

@@ -1,0 +1,173 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's golden outputs.
+
+Tolerances (FP64 throughout; the only difference between device and oracle is summation order):
+  * one EM pass from the same theta:      |dtheta| <= 1e-12 * theta + 1e-300
+  * solve vs the reference's .fpkm:       SURVEY.md 8c criterion (likelihood parity, 1e-5 rel + 1.5e-6 abs off
+                                          the reference's own noise mask, segment expected counts)
+  * iEUMA / TPM / iReadcount:             1e-12 relative (same arithmetic, different summation order)
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from emsar_amd import EmsarHip, EmsarHipError, synth
+from emsar_amd.hip import LAYOUT_CSR, LAYOUT_WINDOWED
+
+pytestmark = pytest.mark.gpu
+LAYOUTS = [LAYOUT_CSR, LAYOUT_WINDOWED]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    ctx = EmsarHip(0)
+    yield ctx
+    ctx.close()
+
+
+def _upload(dev, m, layout):
+    dev.upload_structure(m.n_tx, m.row_ptr, m.col_idx, layout)
+    dev.upload_sample(m.R, m.E, None)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_single_pass_matches_oracle(dev, golden, layout):
+    m = golden.model
+    _upload(dev, m, layout)
+    den = m.den()
+    th = np.where(den > 0, 1.0, 0.0)
+    np.testing.assert_array_equal(dev.get_theta(), th)          # uniform start, zeros outside F
+    for _ in range(5):
+        th, ll = m.em_step(th, den)
+        _, ll_dev = dev.run_passes(1, want_loglik=True)
+        got = dev.get_theta()
+        assert np.all(np.abs(got - th) <= 1e-12 * np.abs(th) + 1e-300)
+        assert abs(ll_dev - ll) <= 1e-11 * abs(ll) + 1e-9
+        dev.set_theta(th)                                         # keep both on the identical trajectory
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("accel", [0, 1])
+def test_solve_meets_reference_parity(dev, golden, layout, accel):
+    m = golden.model
+    _upload(dev, m, layout)
+    th, st = dev.solve(max_iter=600000, accel=accel, tol=1e-10, check_every=16)
+    assert st.converged == 1
+    golden.check_fpkm_parity(th, "hip layout=%d accel=%d" % (layout, accel))
+    F = m.loglik(th)
+    assert abs(st.loglik - F) <= 1e-9 * abs(F)                    # device-side F equals Fp's definition
+    th_o, st_o = m.em_solve(max_iter=600000, accel=accel, tol=1e-10)
+    assert np.all(np.abs(th - th_o) <= 1e-6 * np.abs(th_o) + 1.5e-6)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_postprocessing_matches_oracle_and_reference(dev, golden, layout):
+    m = golden.model
+    _upload(dev, m, layout)
+    ie = dev.ieuma(m.L)
+    np.testing.assert_allclose(ie, m.ieuma(), rtol=1e-12, atol=0)
+    assert np.abs(ie - golden.runs[0]["efflen"]).max() <= 5.01e-7   # column 4 of the reference's .fpkm
+    ref = golden.runs[0]
+    tpm, ir, iri = dev.normalise(ref["fpkm"], ie, golden.N)
+    mean, sd, ir_o, iri_o, tpm_o = O.fpkm_table(np.array([ref["fpkm"]] * 4), ie, golden.N)
+    np.testing.assert_allclose(tpm, tpm_o, rtol=1e-12)
+    np.testing.assert_allclose(ir, ir_o, rtol=1e-12)
+    assert (iri == iri_o).all()
+    # against the reference's own columns (printed with 6 decimals from its unrounded mean)
+    assert np.all(np.abs(tpm - ref["tpm"]) <= 1e-6 * np.abs(ref["tpm"]) + 2e-6)
+    assert np.all(np.abs(ir - ref["ireadcount"]) <= 1e-6 * np.abs(ref["ireadcount"]) + 2e-6)
+
+
+def test_known_answers_and_edge_cases(dev):
+    for layout in LAYOUTS:
+        # closed form R/E, all-zero set, E==0 row, duplicate tid
+        dev.upload_structure(4, [0, 1, 2, 4, 6, 6], [0, 1, 1, 2, 3, 3], layout)   # last row empty
+        dev.upload_sample([7, 0, 0, 8, 5], [2.0, 3.0, 1.5, 2.0, 1.0], None)
+        th, st = dev.solve(max_iter=2000, accel=0, tol=1e-14)
+        assert th[0] == 3.5 and th[1] == 0 and th[2] == 0
+        assert abs(th[3] - 2.0) < 1e-14
+        dev.upload_structure(2, [0, 1, 2], [0, 1], layout)
+        dev.upload_sample([5, 9], [1.0, 0.0], None)
+        th, _ = dev.solve(max_iter=100, accel=1, tol=1e-14)
+        assert th[0] == 5.0 and th[1] == 0.0
+        # empty matrix
+        dev.upload_structure(3, [0], [], layout)
+        dev.upload_sample(None, None, None)
+        th, _ = dev.solve(max_iter=10)
+        assert (th == 0).all()
+
+
+def test_error_paths(dev):
+    fresh = EmsarHip(0)
+    with pytest.raises(EmsarHipError) as e:
+        fresh.upload_sample(None, None, None)                      # no structure yet
+    assert e.value.status == -5
+    with pytest.raises(EmsarHipError) as e:
+        fresh.upload_structure(2, [0, 1], [2])                     # tid out of range never reaches a kernel
+    assert e.value.status == -1
+    fresh.upload_structure(2, [0, 1], [1])
+    with pytest.raises(EmsarHipError):
+        fresh.upload_sample(np.array([-1], dtype=np.int32), None, None)
+    fresh.close()
+    with pytest.raises(EmsarHipError) as e:
+        EmsarHip(999)
+    assert e.value.status == -2
+
+
+@pytest.mark.parametrize("name,scale", [("cfg2", 0.05), ("cfg3", 0.004)])
+def test_synthetic_read_level_matches_oracle(dev, name, scale):
+    s = synth.make_config(name, scale)
+    m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
+    den = s["den"]
+    th0 = np.ones(s["n_tx"])
+    want, ll = m.em_step(th0, den, n_threads=4)
+    want2, _ = m.em_step(want, den, n_threads=4)
+    for layout in LAYOUTS:
+        dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], layout)
+        dev.upload_sample(None, None, den)
+        dev.run_passes(2)
+        got = dev.get_theta()
+        assert np.all(np.abs(got - want2) <= 1e-11 * np.abs(want2) + 1e-300)
+
+
+def test_collapsed_and_read_level_agree(dev):
+    # the reference solves the collapsed (segment) form; the read-level matrix must give the same EM
+    s = synth.make_matrix(n_tx=800, n_reads=30000, law="human", xfam=0.02, seed=4)
+    rp, ci, cnt = synth.collapse(s["row_ptr"], s["col_idx"])
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_WINDOWED)
+    dev.upload_sample(None, None, s["den"])
+    dev.run_passes(25)
+    a = dev.get_theta()
+    dev.upload_structure(s["n_tx"], rp, ci, LAYOUT_WINDOWED)
+    dev.upload_sample(cnt, None, s["den"])
+    dev.run_passes(25)
+    b = dev.get_theta()
+    assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
+
+
+def test_full_size_properties_cfg2(dev):
+    """BASELINE config 2 at full size (5M reads x 80k transcripts): properties that need no oracle."""
+    s = synth.make_config("cfg2", 1.0)
+    n_reads, den = s["n_reads"], s["den"]
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_WINDOWED)
+    dev.upload_sample(None, None, den)
+    info = dev.info()
+    assert info["padded_entries"] <= 1.1 * info["nnz"]
+    prev_ll = -np.inf
+    for _ in range(6):
+        _, ll = dev.run_passes(1, want_loglik=True)                # ll is evaluated at the pass input
+        th = dev.get_theta()
+        assert np.isfinite(th).all() and (th >= 0).all()
+        # mass conservation: sum_t theta_t den_t = number of reads, after every M-step
+        assert abs((th * den).sum() - n_reads) <= 1e-9 * n_reads
+        # EM monotonicity: F = sum log S - sum theta*den, the second term is constant after a pass
+        assert ll >= prev_ll - 1e-9 * abs(ll)
+        prev_ll = ll
+    # layout independence at full size: the CSR kernel walks the rows in the caller's order
+    dev.reset_theta()
+    dev.run_passes(3)
+    a = dev.get_theta()
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_CSR)
+    dev.upload_sample(None, None, den)
+    dev.run_passes(3)
+    b = dev.get_theta()
+    assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
