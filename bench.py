@@ -132,7 +132,9 @@ def cpu_baseline(s, nnz):
     """The CPU oracle's EM pass (oracle/em_oracle.c, OpenMP) on the same matrix, bounded to ~10-30 s."""
     import numpy as np
     import oracle as O
-    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    # a one-GPU box owns a 16-core share of its host (the pool's rule for worker counts); never more threads
+    # than that, whatever os.cpu_count() says about the whole machine
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), int(os.environ.get("EMSAR_CPU_THREADS", "16")))
     m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
     th = np.ones(s["n_tx"])
     th, _ = m.em_step(th, s["den"], n_threads=cores)     # untimed warm pass

@@ -117,6 +117,7 @@ class EmsarHip:
             raise EmsarHipError(rc, "emsar_hip_create")
         self._h = h
         self.n_tx = 0
+        self.n_rows = 0
 
     def close(self):
         if getattr(self, "_h", None):
