@@ -32,7 +32,7 @@ namespace {
 using emsar::Chunk;
 constexpr int kPassThreads = 512;     // 8 waves per workgroup
 constexpr int kDefaultWindow = 4096;  // 2 x 32 KiB of LDS per workgroup -> 2 workgroups per CU
-constexpr int64_t kChunkEntries = 32768;
+constexpr int64_t kChunkEntries = 65536;
 
 // ------------------------------------------------------------------------------------------------
 // device scalars of one solve (lives in HBM, polled by the host every check_every cycles)
@@ -77,10 +77,69 @@ enum PassMode { MODE_EM = 0, MODE_EM_LL = 1, MODE_SCATTER = 2 };
 // ------------------------------------------------------------------------------------------------
 // k_pass_windowed: one EM pass (or a plain row-value scatter) over the WINDOWED layout.
 //   chunks[blockIdx.x]  -> slices [slice_begin, +n_slices), LDS window [lo, lo+width)
-//   lane l of a wave owns row slice*64+l; its j-th tid is ent[slice_off[slice] + j*64 + l]
-// HBM traffic per pass: ent once (4 B per stored slot), slice_off (8 B per 64 rows), optional row weights;
+//   a wave owns one 256-row slice at a time; lane l handles rows 4l..4l+3 of it; the j-th tids of those four
+//   rows are ONE int4 at ent[slice_off + j*256 + 4l]  (1 KiB contiguous per wave load)
+// Up to 8 loads (8 KiB per wave) are issued before the first use, the tids then stay in registers for both
+// the E-step sums and the M-step adds; rows longer than 8 are streamed in segments of 8 and re-read (L2) for
+// the adds.
+// HBM traffic per pass: ent once (4 B per stored slot), slice_off (8 B per 256 rows), optional row weights;
 // theta window loads and acc window flushes are O(n_tx + chunks*family) and stay in L2.
 // ------------------------------------------------------------------------------------------------
+constexpr int kSeg = 8;  // int4 loads in flight per lane
+
+struct Window {
+    const double *th_w; double *acc_w; const double *theta; double *acc; int lo; unsigned width;
+    __device__ __forceinline__ double get(int t) const {
+        unsigned d = (unsigned)(t - lo);
+        return d < width ? th_w[d] : theta[t];
+    }
+    __device__ __forceinline__ void add(int t, double v) const {
+        unsigned d = (unsigned)(t - lo);
+        if (d < width) lds_add_f64(&acc_w[d], v);
+        else atomic_add_f64(&acc[t], v);
+    }
+};
+
+__device__ __forceinline__ void load_seg(int4 (&q)[kSeg], const int4 *e, int n) {
+#pragma unroll
+    for (int j = 0; j < kSeg; j++)
+        if (j < n) q[j] = e[(size_t)j * 64];   // n is wave-uniform: scalar branch, loads stay independent
+}
+
+__device__ __forceinline__ void sum_seg(const int4 (&q)[kSeg], int n, const Window &W, double (&S)[4]) {
+#pragma unroll
+    for (int j = 0; j < kSeg; j++) {
+        if (j < n) {
+            int4 t = q[j];
+            if (t.x >= 0) S[0] += W.get(t.x);
+            if (t.y >= 0) S[1] += W.get(t.y);
+            if (t.z >= 0) S[2] += W.get(t.z);
+            if (t.w >= 0) S[3] += W.get(t.w);
+        }
+    }
+}
+
+// M-step adds of one segment.  The four rows of a lane are neighbours in the sorted order and often carry
+// the same tid in column j: equal neighbours are merged in registers first, so that one LDS atomic carries
+// up to four contributions (an LDS f64 atomic costs ~6 cycles per extra lane on the same address).
+__device__ __forceinline__ void add_seg(const int4 (&q)[kSeg], int n, const Window &W, const double (&w)[4]) {
+#pragma unroll
+    for (int j = 0; j < kSeg; j++) {
+        if (j < n) {
+            int4 t = q[j];
+            double v0 = t.x >= 0 ? w[0] : 0.0, v1 = t.y >= 0 ? w[1] : 0.0;
+            double v2 = t.z >= 0 ? w[2] : 0.0, v3 = t.w >= 0 ? w[3] : 0.0;
+            if (t.y == t.x) { v1 += v0; v0 = 0.0; }
+            if (t.z == t.y) { v2 += v1; v1 = 0.0; }
+            if (t.w == t.z) { v3 += v2; v2 = 0.0; }
+            if (v0 != 0.0) W.add(t.x, v0);
+            if (v1 != 0.0) W.add(t.y, v1);
+            if (v2 != 0.0) W.add(t.z, v2);
+            if (v3 != 0.0) W.add(t.w, v3);
+        }
+    }
+}
+
 template <int THREADS, bool WEIGHTED, int MODE>
 __global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restrict__ chunks,
                                                            const uint64_t *__restrict__ slice_off,
@@ -102,38 +161,50 @@ __global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restri
         acc_w[i] = 0.0;
     }
     __syncthreads();
+    const Window W{th_w, acc_w, theta, acc, lo, (unsigned)width};
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double ll = 0.0;
     for (uint32_t s = wave; s < c.n_slices; s += THREADS / 64) {
         const uint32_t gs = c.slice_begin + s;
         const uint64_t off = slice_off[gs];
-        const int k = (int)((slice_off[gs + 1] - off) >> 6);
-        const int32_t *e = ent + off + lane;
-        double w;
+        const int k = (int)((slice_off[gs + 1] - off) >> 8);
+        const int4 *e = reinterpret_cast<const int4 *>(ent + off) + lane;
+        const uint64_t row0 = (uint64_t)gs * 256 + 4 * lane;
+        int4 q[kSeg];
+        double w[4];
+        load_seg(q, e, k < kSeg ? k : kSeg);
         if (MODE == MODE_SCATTER) {
-            w = rowval[(uint64_t)gs * 64 + lane];
+            const double2 *rv = reinterpret_cast<const double2 *>(rowval + row0);
+            double2 a = rv[0], b = rv[1];
+            w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
         } else {
-            double S = 0.0;
-            for (int j = 0; j < k; j++) {
-                int t = e[(size_t)j * 64];
-                if (t >= 0) {
-                    unsigned d = (unsigned)(t - lo);
-                    S += (d < (unsigned)width) ? th_w[d] : theta[t];
-                }
+            double S[4] = {0.0, 0.0, 0.0, 0.0};
+            sum_seg(q, k < kSeg ? k : kSeg, W, S);
+            for (int j0 = kSeg; j0 < k; j0 += kSeg) {          // long rows: stream the remaining segments
+                int n = k - j0 < kSeg ? k - j0 : kSeg;
+                load_seg(q, e + (size_t)j0 * 64, n);
+                sum_seg(q, n, W, S);
             }
-            double r = WEIGHTED ? (double)wgt[(uint64_t)gs * 64 + lane] : 1.0;
-            bool live = (S > 0.0) && (r > 0.0);
-            w = live ? r / S : 0.0;
-            if (MODE == MODE_EM_LL && live) ll += r * log(S);
+            double r[4] = {1.0, 1.0, 1.0, 1.0};
+            if (WEIGHTED) {
+                int4 rw = *reinterpret_cast<const int4 *>(wgt + row0);
+                r[0] = rw.x; r[1] = rw.y; r[2] = rw.z; r[3] = rw.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                bool live = (S[i] > 0.0) && (r[i] > 0.0);
+                w[i] = live ? r[i] / S[i] : 0.0;
+                if (MODE == MODE_EM_LL && live) ll += r[i] * log(S[i]);
+            }
         }
-        if (w != 0.0) {
-            for (int j = 0; j < k; j++) {
-                int t = e[(size_t)j * 64];
-                if (t < 0) break;  // padding is always at the tail of a row
-                unsigned d = (unsigned)(t - lo);
-                if (d < (unsigned)width) lds_add_f64(&acc_w[d], w);
-                else atomic_add_f64(&acc[t], w);
+        if (k <= kSeg) {
+            add_seg(q, k, W, w);
+        } else {
+            for (int j0 = 0; j0 < k; j0 += kSeg) {
+                int n = k - j0 < kSeg ? k - j0 : kSeg;
+                load_seg(q, e + (size_t)j0 * 64, n);
+                add_seg(q, n, W, w);
             }
         }
     }
@@ -189,21 +260,28 @@ __global__ void k_fill_start(int n, const double *__restrict__ den, double *__re
 }
 
 // theta_out = theta_in * acc / den ; acc <- 0 ; scal.delta = max |dtheta| / (theta_out + floor)
+// grid-stride, one atomicMax per workgroup (hundreds of same-address atomics cost ~12 ns each)
 __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
                                                 const double *__restrict__ den, double *__restrict__ th_out,
                                                 double abs_floor, Scal *scal) {
-    int t = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double red[4];
     double d = 0.0;
-    if (t < n) {
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
         double a = acc[t], dn = den[t], x = th_in[t];
         double y = dn > 0.0 ? x * a / dn : 0.0;
         th_out[t] = y;
         acc[t] = 0.0;
-        d = fabs(y - x) / (fabs(y) + abs_floor);
-        if (!(d == d)) d = __builtin_huge_val();  // NaN -> +inf so that the host sees it
+        double dd = fabs(y - x) / (fabs(y) + abs_floor);
+        if (!(dd == dd)) dd = __builtin_huge_val();  // NaN -> +inf so that the host sees it
+        d = fmax(d, dd);
     }
     for (int o = 32; o > 0; o >>= 1) d = fmax(d, __shfl_xor(d, o, 64));
-    if ((threadIdx.x & 63) == 0 && d > 0.0) atomicMax(&scal->delta_bits, (unsigned long long)__double_as_longlong(d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        if (d > 0.0) atomicMax(&scal->delta_bits, (unsigned long long)__double_as_longlong(d));
+    }
 }
 
 __global__ void k_cycle_begin(Scal *s) {
@@ -402,7 +480,7 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
 int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_ll, int ll_slot, double abs_floor) {
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot]);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_update, dim3(grid_for(ctx->n_tx, 256)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
+    hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
                        ctx->d_den, th_out, abs_floor, ctx->d_scal);
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;

@@ -5,9 +5,10 @@
 // transcript ids, so rows may be stored in any order.  We choose the order for the hardware:
 //
 //   rows are sorted by (block(min tid), length class, min tid)      [two stable counting-sort passes]
-//   consecutive groups of 64 sorted rows form a SLICE, stored column-major:
-//        entry j of the row handled by lane l  ->  ent[slice_off + j*64 + l]     (-1 = padding)
-//     so that one wave reads 256 contiguous bytes per step and no row_ptr is needed at run time
+//   consecutive groups of 256 sorted rows form a SLICE, stored column-major:
+//        entry j of row i of the slice  ->  ent[slice_off + j*256 + i]           (-1 = padding)
+//     lane l of the wave that owns the slice handles rows 4l..4l+3: its j-th load is ONE 16-byte int4, the
+//     wave reads 1 KiB contiguous per load instruction, and no row_ptr is needed at run time
 //   consecutive slices form a CHUNK (one workgroup); every tid of a chunk is >= chunk.lo, and tids in
 //     [lo, lo+width) are served from LDS copies of theta / the M-step accumulator ("near"), the few
 //     others ("far", cross-family alignments) go to L2/HBM directly.
@@ -19,12 +20,12 @@
 
 namespace emsar {
 
-constexpr int kSliceRows = 64;     // one wavefront
+constexpr int kSliceRows = 256;    // one wavefront, 4 rows per lane (16-byte loads)
 constexpr int kMinBlockTids = 256;  // smallest sort granularity in tid space
 constexpr int kLenClasses = 64;
 
 struct Chunk {             // 16 bytes, read once per workgroup
-    uint32_t slice_begin;  // first slice (global slice index); row index = slice*64 + lane
+    uint32_t slice_begin;  // first slice (global slice index); sorted-row index = slice*256 + 4*lane + i
     uint32_t n_slices;
     int32_t lo;            // first tid of the LDS window
     int32_t width;         // window length in tids (<= window)
@@ -36,7 +37,7 @@ struct WindowedLayout {
     int32_t block_tids = kMinBlockTids;  // rows are bucketed by min_tid / block_tids
     int64_t n_sorted_rows = 0;           // rows with at least one tid
     std::vector<uint32_t> perm;          // sorted position -> original row
-    std::vector<uint64_t> slice_off;     // n_slices+1 entry offsets (multiples of 64)
+    std::vector<uint64_t> slice_off;     // n_slices+1 entry offsets (multiples of 256)
     std::vector<int32_t> ent;            // padded column-major entries
     std::vector<Chunk> chunks;
     int64_t far_entries = 0;
@@ -81,9 +82,9 @@ inline int build_windowed(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr,
     }
     out.n_sorted_rows = n_act;
     // Sort granularity: a (block, length-class) bucket should hold many 64-row slices, otherwise slices mix
-    // lengths and pad.  Aim at >= 4096 rows per block; never wider than the LDS window.
+    // lengths and pad.  Aim at >= 16384 rows per block; never wider than the LDS window.
     {
-        int64_t want = n_act > 0 ? (4096 * (int64_t)n_tx + n_act - 1) / n_act : kMinBlockTids;
+        int64_t want = n_act > 0 ? (16384 * (int64_t)n_tx + n_act - 1) / n_act : kMinBlockTids;
         int32_t b = kMinBlockTids;
         while (b < want && b * 2 <= window) b *= 2;
         out.block_tids = std::min(b, window);

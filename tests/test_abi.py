@@ -74,7 +74,7 @@ def test_layout_roundtrip_synthetic(lib, window, chunk):
     assert info["nnz"] == nnz and info["padded_entries"] >= nnz
     if window == 0:
         assert info["padded_entries"] <= 1.35 * nnz       # length-sorted slices keep padding small
-    assert info["n_slices"] == (m["n_reads"] + 63) // 64
+    assert info["n_slices"] == (m["n_reads"] + 255) // 256
     if window == 256:
         assert info["far_entries"] > 0                    # cross-family hits fall outside a small window
 
@@ -89,7 +89,7 @@ def test_layout_roundtrip_edge_cases(lib):
     long_row = rng.integers(0, 3000, 700).astype(np.int32)
     rp = np.array([0, 700, 701], dtype=np.uint64)
     info = emsar_amd.layout_selfcheck(3000, rp, np.append(long_row, 5).astype(np.int32))
-    assert info["n_slices"] == 1 and info["padded_entries"] == 64 * 700
+    assert info["n_slices"] == 1 and info["padded_entries"] == 256 * 700
 
 
 def test_layout_roundtrip_golden(lib, golden):
