@@ -100,44 +100,118 @@ struct Window {
     }
 };
 
-__device__ __forceinline__ void load_seg(int4 (&q)[kSeg], const int4 *e, int n) {
+// The segment length n (1..8) is wave-uniform; each length gets its own straight-line code so that all n
+// loads are issued back to back (n KiB in flight per wave) with no control flow between them.
+template <int N>
+__device__ __forceinline__ void load_n(int4 (&q)[N], const int4 *e) {
 #pragma unroll
-    for (int j = 0; j < kSeg; j++)
-        if (j < n) q[j] = e[(size_t)j * 64];   // n is wave-uniform: scalar branch, loads stay independent
+    for (int j = 0; j < N; j++) q[j] = e[(size_t)j * 64];
 }
 
-__device__ __forceinline__ void sum_seg(const int4 (&q)[kSeg], int n, const Window &W, double (&S)[4]) {
+template <int N>
+__device__ __forceinline__ void sum_n(const int4 (&q)[N], const Window &W, double (&S)[4]) {
 #pragma unroll
-    for (int j = 0; j < kSeg; j++) {
-        if (j < n) {
-            int4 t = q[j];
-            if (t.x >= 0) S[0] += W.get(t.x);
-            if (t.y >= 0) S[1] += W.get(t.y);
-            if (t.z >= 0) S[2] += W.get(t.z);
-            if (t.w >= 0) S[3] += W.get(t.w);
-        }
+    for (int j = 0; j < N; j++) {
+        int4 t = q[j];
+        if (t.x >= 0) S[0] += W.get(t.x);
+        if (t.y >= 0) S[1] += W.get(t.y);
+        if (t.z >= 0) S[2] += W.get(t.z);
+        if (t.w >= 0) S[3] += W.get(t.w);
     }
 }
 
 // M-step adds of one segment.  The four rows of a lane are neighbours in the sorted order and often carry
 // the same tid in column j: equal neighbours are merged in registers first, so that one LDS atomic carries
 // up to four contributions (an LDS f64 atomic costs ~6 cycles per extra lane on the same address).
-__device__ __forceinline__ void add_seg(const int4 (&q)[kSeg], int n, const Window &W, const double (&w)[4]) {
+template <int N>
+__device__ __forceinline__ void add_n(const int4 (&q)[N], const Window &W, const double (&w)[4]) {
 #pragma unroll
-    for (int j = 0; j < kSeg; j++) {
-        if (j < n) {
-            int4 t = q[j];
-            double v0 = t.x >= 0 ? w[0] : 0.0, v1 = t.y >= 0 ? w[1] : 0.0;
-            double v2 = t.z >= 0 ? w[2] : 0.0, v3 = t.w >= 0 ? w[3] : 0.0;
-            if (t.y == t.x) { v1 += v0; v0 = 0.0; }
-            if (t.z == t.y) { v2 += v1; v1 = 0.0; }
-            if (t.w == t.z) { v3 += v2; v2 = 0.0; }
-            if (v0 != 0.0) W.add(t.x, v0);
-            if (v1 != 0.0) W.add(t.y, v1);
-            if (v2 != 0.0) W.add(t.z, v2);
-            if (v3 != 0.0) W.add(t.w, v3);
-        }
+    for (int j = 0; j < N; j++) {
+        int4 t = q[j];
+        double v0 = t.x >= 0 ? w[0] : 0.0, v1 = t.y >= 0 ? w[1] : 0.0;
+        double v2 = t.z >= 0 ? w[2] : 0.0, v3 = t.w >= 0 ? w[3] : 0.0;
+        if (t.y == t.x) { v1 += v0; v0 = 0.0; }
+        if (t.z == t.y) { v2 += v1; v1 = 0.0; }
+        if (t.w == t.z) { v3 += v2; v2 = 0.0; }
+        if (v0 != 0.0) W.add(t.x, v0);
+        if (v1 != 0.0) W.add(t.y, v1);
+        if (v2 != 0.0) W.add(t.z, v2);
+        if (v3 != 0.0) W.add(t.w, v3);
     }
+}
+
+template <bool WEIGHTED, int MODE>
+__device__ __forceinline__ void row_weights(const double (&S)[4], const int32_t *wgt, uint64_t row0, double (&w)[4], double &ll) {
+    double r[4] = {1.0, 1.0, 1.0, 1.0};
+    if (WEIGHTED) {
+        int4 rw = *reinterpret_cast<const int4 *>(wgt + row0);
+        r[0] = rw.x; r[1] = rw.y; r[2] = rw.z; r[3] = rw.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        bool live = (S[i] > 0.0) && (r[i] > 0.0);
+        w[i] = live ? r[i] / S[i] : 0.0;
+        if (MODE == MODE_EM_LL && live) ll += r[i] * log(S[i]);
+    }
+}
+
+__device__ __forceinline__ void scatter_weights(const double *rowval, uint64_t row0, double (&w)[4]) {
+    const double2 *rv = reinterpret_cast<const double2 *>(rowval + row0);
+    double2 a = rv[0], b = rv[1];
+    w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
+}
+
+// A slice whose rows have at most 8 tids: all N loads (N KiB per wave) are issued back to back, the tids stay
+// in registers for the E-step sums and the M-step adds.  One straight-line instance per N.
+template <int N, bool WEIGHTED, int MODE>
+__device__ __forceinline__ void slice_short(const int4 *e, uint64_t row0, const Window &W, const int32_t *wgt,
+                                            const double *rowval, double &ll) {
+    int4 q[N];
+    double w[4];
+    load_n<N>(q, e);
+    if (MODE == MODE_SCATTER) {
+        scatter_weights(rowval, row0, w);
+    } else {
+        double S[4] = {0.0, 0.0, 0.0, 0.0};
+        sum_n<N>(q, W, S);
+        row_weights<WEIGHTED, MODE>(S, wgt, row0, w, ll);
+    }
+    add_n<N>(q, W, w);
+}
+
+// Rows with more than 8 tids: streamed in segments of 8 loads for the sums, re-read (L2) for the adds.
+template <bool WEIGHTED, int MODE>
+__device__ __forceinline__ void slice_long(const int4 *e, int k, uint64_t row0, const Window &W, const int32_t *wgt,
+                                           const double *rowval, double &ll) {
+    double w[4];
+    const int nfull = k / kSeg, rem = k % kSeg;
+    if (MODE == MODE_SCATTER) {
+        scatter_weights(rowval, row0, w);
+    } else {
+        double S[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int g = 0; g < nfull; g++) {
+            int4 q[kSeg];
+            load_n<kSeg>(q, e + (size_t)g * kSeg * 64);
+            sum_n<kSeg>(q, W, S);
+        }
+        for (int j = nfull * kSeg; j < k; j++) {
+            int4 q[1];
+            load_n<1>(q, e + (size_t)j * 64);
+            sum_n<1>(q, W, S);
+        }
+        row_weights<WEIGHTED, MODE>(S, wgt, row0, w, ll);
+    }
+    for (int g = 0; g < nfull; g++) {
+        int4 q[kSeg];
+        load_n<kSeg>(q, e + (size_t)g * kSeg * 64);
+        add_n<kSeg>(q, W, w);
+    }
+    for (int j = nfull * kSeg; j < k; j++) {
+        int4 q[1];
+        load_n<1>(q, e + (size_t)j * 64);
+        add_n<1>(q, W, w);
+    }
+    (void)rem;
 }
 
 template <int THREADS, bool WEIGHTED, int MODE>
@@ -163,7 +237,8 @@ __global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restri
     __syncthreads();
     const Window W{th_w, acc_w, theta, acc, lo, (unsigned)width};
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // keep slice bookkeeping in SGPRs
     double ll = 0.0;
     for (uint32_t s = wave; s < c.n_slices; s += THREADS / 64) {
         const uint32_t gs = c.slice_begin + s;
@@ -171,42 +246,13 @@ __global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restri
         const int k = (int)((slice_off[gs + 1] - off) >> 8);
         const int4 *e = reinterpret_cast<const int4 *>(ent + off) + lane;
         const uint64_t row0 = (uint64_t)gs * 256 + 4 * lane;
-        int4 q[kSeg];
-        double w[4];
-        load_seg(q, e, k < kSeg ? k : kSeg);
-        if (MODE == MODE_SCATTER) {
-            const double2 *rv = reinterpret_cast<const double2 *>(rowval + row0);
-            double2 a = rv[0], b = rv[1];
-            w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
-        } else {
-            double S[4] = {0.0, 0.0, 0.0, 0.0};
-            sum_seg(q, k < kSeg ? k : kSeg, W, S);
-            for (int j0 = kSeg; j0 < k; j0 += kSeg) {          // long rows: stream the remaining segments
-                int n = k - j0 < kSeg ? k - j0 : kSeg;
-                load_seg(q, e + (size_t)j0 * 64, n);
-                sum_seg(q, n, W, S);
-            }
-            double r[4] = {1.0, 1.0, 1.0, 1.0};
-            if (WEIGHTED) {
-                int4 rw = *reinterpret_cast<const int4 *>(wgt + row0);
-                r[0] = rw.x; r[1] = rw.y; r[2] = rw.z; r[3] = rw.w;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                bool live = (S[i] > 0.0) && (r[i] > 0.0);
-                w[i] = live ? r[i] / S[i] : 0.0;
-                if (MODE == MODE_EM_LL && live) ll += r[i] * log(S[i]);
-            }
+#define EMSAR_SHORT(NN) case NN: slice_short<NN, WEIGHTED, MODE>(e, row0, W, wgt, rowval, ll); break;
+        switch (k) {
+            EMSAR_SHORT(1) EMSAR_SHORT(2) EMSAR_SHORT(3) EMSAR_SHORT(4)
+            EMSAR_SHORT(5) EMSAR_SHORT(6) EMSAR_SHORT(7) EMSAR_SHORT(8)
+            default: slice_long<WEIGHTED, MODE>(e, k, row0, W, wgt, rowval, ll); break;
         }
-        if (k <= kSeg) {
-            add_seg(q, k, W, w);
-        } else {
-            for (int j0 = 0; j0 < k; j0 += kSeg) {
-                int n = k - j0 < kSeg ? k - j0 : kSeg;
-                load_seg(q, e + (size_t)j0 * 64, n);
-                add_seg(q, n, W, w);
-            }
-        }
+#undef EMSAR_SHORT
     }
     __syncthreads();
     for (int i = threadIdx.x; i < width; i += THREADS) {
