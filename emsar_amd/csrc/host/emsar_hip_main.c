@@ -1,0 +1,266 @@
+/* emsar_hip_main.c -- command-line driver: the per-sample loop of the reference's main()
+ * (/root/reference/src/emsar_main.c:380-488) with run_MLE_threads() replaced by the HIP library.
+ *
+ *   emsar-hip [options] -I index.rsh outdir outprefix alignmentfile            (single sample)
+ *   emsar-hip [options] -M -I index.rsh outdir outprefix alignmentfilelist     (one alignment file per line)
+ *
+ * Same option letters as the reference for everything that reaches this path (emsar_main.c:100-214):
+ *   -I rsh  -P  -s strand  -k max_repeat  -n rounds  -e tol  -i max_passes  -d delta  -g  -M  -S  -q  -v  -p threads(ignored)
+ * plus  --gpus N (devices used by -M, default all), --device D (single sample), --plain (no SQUAREM),
+ *       --stats-json FILE.
+ * Not taken over: -x fasta (index build, emsar-build's job), -B BAM (use -S with SAM text), -m positional bias
+ * (unfinished in the reference, emsar_main.c:371), -F/-f (the reference overwrites both from the rsh header,
+ * emsar_functions.c:1419-1420, so they have no effect with -I).
+ *
+ * Outputs: <outdir>/<prefix>.<i>.fpkm, .fraglength_effect and, with -g, .segments -- i = 0-based index of the
+ * alignment file (emsar_main.c:459-469).  Column 3 (sd.of.FPKM) is 0: the EM is deterministic, the reference's
+ * spread comes from its random restarts (documented deviation).
+ *
+ * -M: samples are independent (emsar_main.c:380-488 resets every count per file), so sample i runs on GPU
+ * i mod G with one host thread per GPU; no collective.  The only cross-sample state of the reference, EUMAcut
+ * (never reset, emsar_main.c:95,418), is carried in sample order.
+ */
+#include <getopt.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+
+#include "../../../include/emsar_hip.h"
+#include "emsar_host.h"
+
+typedef struct {
+    const char *rsh_path, *outdir, *prefix;
+    char **aln; int n_aln;
+    emsar_aln_opts ao;
+    int n_round, delta, print_segments, verbose, accel;
+    double tol; int max_iter;
+    const char *stats_json;
+} config;
+
+typedef struct {
+    config *cfg; const emsar_rsh *rsh;
+    int device, n_workers, worker;
+    /* ordered hand-over of EUMAcut between samples */
+    pthread_mutex_t *mu; pthread_cond_t *cv; int *next_model; double *eumacut;
+    int *status;          /* per sample */
+    emsar_em_stats *stats; /* per sample */
+    double *parse_s;
+} worker_arg;
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i) {
+    config *cfg = w->cfg; const emsar_rsh *r = w->rsh;
+    char err[512] = "", path[4096];
+    emsar_counts *cnt = NULL; emsar_model *m = NULL;
+    double *theta = NULL, *rounds = NULL, *mean = NULL, *sd = NULL, *ieuma = NULL, *tpm = NULL, *ir = NULL; int32_t *iri = NULL;
+    int rc;
+    double t0 = now_s();
+    rc = emsar_count_alignments(r, cfg->aln[i], &cfg->ao, &cnt, err, sizeof err);
+    w->parse_s[i] = now_s() - t0;
+    /* model preparation in sample order (EUMAcut carries over) */
+    pthread_mutex_lock(w->mu);
+    while (*w->next_model != i) pthread_cond_wait(w->cv, w->mu);
+    if (rc == 0) rc = emsar_model_build(r, cnt, cfg->delta, w->eumacut, &m, err, sizeof err);
+    (*w->next_model)++;
+    pthread_cond_broadcast(w->cv);
+    pthread_mutex_unlock(w->mu);
+    if (rc) { fprintf(stderr, "alnfile[%d]=%s: %s\n", i, cfg->aln[i], err); goto done; }
+    if (cfg->verbose > 0)
+        fprintf(stdout, "alnfile[%d]=%s  reads=%lld (seen %lld, >k %lld, bad fraglen %lld, discrepant %lld, no segment %lld)  sets=%d  gpu=%d\n",
+                i, cfg->aln[i], (long long)cnt->total_reads, (long long)cnt->reads_seen, (long long)cnt->reads_over_k,
+                (long long)cnt->reads_bad_fraglen, (long long)cnt->reads_discrepant, (long long)cnt->reads_no_segment, m->n_sets, w->device);
+
+    const size_t T = (size_t)r->n_tx;
+    theta = (double *)malloc(T * 8); mean = (double *)malloc(T * 8); sd = (double *)malloc(T * 8);
+    ieuma = (double *)malloc(T * 8); tpm = (double *)malloc(T * 8); ir = (double *)malloc(T * 8); iri = (int32_t *)malloc(T * 4);
+    rounds = (double *)malloc(T * 8 * (size_t)cfg->n_round);
+    if (!theta || !mean || !sd || !ieuma || !tpm || !ir || !iri || !rounds) { rc = EMSAR_HOST_ERR_OOM; goto done; }
+
+    /* ---- the replaced call: run_MLE_threads() + construct_FPKMfinal, emsar_main.c:444-450 ---- */
+    emsar_em_params p = {cfg->max_iter, cfg->accel, cfg->tol, 0.0, 0, 0};
+    if ((rc = emsar_hip_upload_sample(ctx, cnt->R, m->E_solver, NULL)) ||
+        (rc = emsar_hip_solve(ctx, &p, theta, &w->stats[i]))) {
+        fprintf(stderr, "alnfile[%d]: %s (%s)\n", i, emsar_hip_strerror(rc), emsar_hip_last_error(ctx));
+        goto done;
+    }
+    for (int k = 0; k < cfg->n_round; k++) memcpy(rounds + (size_t)k * T, theta, T * 8);   /* deterministic solver: rounds coincide */
+    emsar_mean_sd(r->n_tx, cfg->n_round, rounds, mean, sd);
+    /* ---- compute_iEUMA + print_FPKMfinal, emsar_main.c:454-460 ---- */
+    if ((rc = emsar_hip_ieuma(ctx, m->L, ieuma)) ||
+        (rc = emsar_hip_normalise(ctx, mean, ieuma, cnt->total_reads, tpm, ir, iri))) {
+        fprintf(stderr, "alnfile[%d]: %s (%s)\n", i, emsar_hip_strerror(rc), emsar_hip_last_error(ctx));
+        goto done;
+    }
+    int64_t tot = 0;
+    snprintf(path, sizeof path, "%s/%s.%d.fpkm", cfg->outdir, cfg->prefix, i);
+    if ((rc = emsar_write_fpkm(path, r, mean, sd, ieuma, ir, iri, tpm, &tot))) { fprintf(stderr, "can't write %s\n", path); goto done; }
+    if (cfg->verbose > 0) fprintf(stdout, "Total inferred readcount=%lld\n", (long long)tot);
+    snprintf(path, sizeof path, "%s/%s.%d.fraglength_effect", cfg->outdir, cfg->prefix, i);
+    if ((rc = emsar_write_fraglength(path, r, cnt, m))) { fprintf(stderr, "can't write %s\n", path); goto done; }
+    if (cfg->print_segments) {
+        snprintf(path, sizeof path, "%s/%s.%d.segments", cfg->outdir, cfg->prefix, i);
+        if ((rc = emsar_write_segments(path, r, cnt, m, mean))) { fprintf(stderr, "can't write %s\n", path); goto done; }
+    }
+    if (cfg->verbose > 0)
+        fprintf(stdout, "Complete: %s/%s.%d.fpkm  (EM passes %d, converged %d, solve %.1f ms, logL %.6f)\n", cfg->outdir, cfg->prefix, i,
+                w->stats[i].iters, w->stats[i].converged, w->stats[i].solve_ms, w->stats[i].loglik);
+done:
+    free(theta); free(rounds); free(mean); free(sd); free(ieuma); free(tpm); free(ir); free(iri);
+    emsar_counts_free(cnt); emsar_model_free(m);
+    return rc;
+}
+
+static void *worker_main(void *a) {
+    worker_arg *w = (worker_arg *)a;
+    emsar_hip_ctx *ctx = NULL;
+    int rc = emsar_hip_create(&ctx, w->device);
+    if (rc == 0) rc = emsar_hip_upload_structure(ctx, w->rsh->n_rows, w->rsh->n_tx, w->rsh->row_ptr, w->rsh->col_idx, EMSAR_LAYOUT_AUTO);
+    if (rc) fprintf(stderr, "GPU %d: %s\n", w->device, emsar_hip_strerror(rc));
+    for (int i = w->worker; i < w->cfg->n_aln; i += w->n_workers) {
+        if (rc) {   /* keep the ordered hand-over alive so the other workers are not stuck */
+            pthread_mutex_lock(w->mu);
+            while (*w->next_model != i) pthread_cond_wait(w->cv, w->mu);
+            (*w->next_model)++;
+            pthread_cond_broadcast(w->cv);
+            pthread_mutex_unlock(w->mu);
+            w->status[i] = rc;
+        } else {
+            w->status[i] = run_sample(w, ctx, i);
+        }
+    }
+    emsar_hip_destroy(ctx);
+    return NULL;
+}
+
+static void usage(const char *a0) {
+    fprintf(stderr,
+            "Usage : %s <options> -I rshfile outdir outprefix alignmentfile|alignmentfilelist\n"
+            "  -I, --rsh <file>        rsh index (from emsar-build)            [required]\n"
+            "  -M, --multisample       last argument lists one alignment file per line; samples are spread over GPUs\n"
+            "  -P, --PE                paired-end          -s, --strand_type ns|ssf|ssr|ssfr|ssrf (default ns)\n"
+            "  -S, --SAM               SAM text input (default: default bowtie output)\n"
+            "  -k, --max_repeat <n>    reads with more alignments are discarded (default 100)\n"
+            "  -n, --nround <n>        rounds reported in the mean/sd columns (default 4; the EM is deterministic)\n"
+            "  -e, --epsilon <tol>     EM stops when max |dtheta|/(theta+1e-6) < tol (default 1e-10)\n"
+            "  -i, --max_niter_mle <n> cap on EM passes (default 200000)\n"
+            "  -d, --delta <d>         10^d scaling of the effective lengths (default 0)\n"
+            "  -g, --print_segments    also write .segments\n"
+            "      --gpus <n> / --device <d> / --plain / --stats-json <file> / -q / -v\n", a0);
+}
+
+int main(int argc, char **argv) {
+    config cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.ao.max_repeat = 100; cfg.n_round = 4; cfg.verbose = 1; cfg.accel = 1; cfg.tol = 1e-10; cfg.max_iter = 200000;
+    const char *strand = "ns"; int multisample = 0, gpus = 0, device = 0;
+    static struct option lo[] = {
+        {"rsh", required_argument, 0, 'I'}, {"PE", no_argument, 0, 'P'}, {"strand_type", required_argument, 0, 's'},
+        {"maxthread", required_argument, 0, 'p'}, {"max_repeat", required_argument, 0, 'k'}, {"nround", required_argument, 0, 'n'},
+        {"epsilon", required_argument, 0, 'e'}, {"max_niter_mle", required_argument, 0, 'i'}, {"delta", required_argument, 0, 'd'},
+        {"print_segments", no_argument, 0, 'g'}, {"multisample", no_argument, 0, 'M'}, {"SAM", no_argument, 0, 'S'},
+        {"verbose", no_argument, 0, 'v'}, {"no_verbose", no_argument, 0, 'q'}, {"gpus", required_argument, 0, 1000},
+        {"device", required_argument, 0, 1001}, {"plain", no_argument, 0, 1002}, {"stats-json", required_argument, 0, 1003},
+        {"maxfraglen", required_argument, 0, 'F'}, {"minfraglen", required_argument, 0, 'f'}, {0, 0, 0, 0}};
+    int c;
+    while ((c = getopt_long(argc, argv, "vqPs:p:F:f:n:e:d:gMSk:i:I:", lo, NULL)) != -1) {
+        switch (c) {
+            case 'I': cfg.rsh_path = optarg; break;
+            case 'P': cfg.ao.pe = 1; break;
+            case 's': strand = optarg; break;
+            case 'p': break;                       /* CPU threads of the reference's solver: no meaning here */
+            case 'F': case 'f': break;             /* overwritten by the rsh header in the reference too */
+            case 'k': cfg.ao.max_repeat = atoi(optarg); break;
+            case 'n': cfg.n_round = atoi(optarg); if (cfg.n_round <= 0) { fprintf(stderr, "option -n must be a natural number.\n"); return 1; } break;
+            case 'e': cfg.tol = atof(optarg); if (cfg.tol <= 0) { fprintf(stderr, "option -e must be positive.\n"); return 1; } break;
+            case 'i': cfg.max_iter = atoi(optarg); if (cfg.max_iter <= 0) { fprintf(stderr, "option -i must be positive.\n"); return 1; } break;
+            case 'd': cfg.delta = atoi(optarg); break;
+            case 'g': cfg.print_segments = 1; break;
+            case 'M': multisample = 1; break;
+            case 'S': cfg.ao.format = 1; break;
+            case 'v': cfg.verbose = 2; break;
+            case 'q': cfg.verbose = 0; break;
+            case 1000: gpus = atoi(optarg); break;
+            case 1001: device = atoi(optarg); break;
+            case 1002: cfg.accel = 0; break;
+            case 1003: cfg.stats_json = optarg; break;
+            default: usage(argv[0]); return 1;
+        }
+    }
+    if (!cfg.rsh_path || optind + 2 >= argc) { usage(argv[0]); return 1; }
+    if (emsar_set_strand(strand, cfg.ao.pe, &cfg.ao.strand)) { fprintf(stderr, "error: invalid strand type.\n"); return 1; }
+    cfg.outdir = argv[optind]; cfg.prefix = argv[optind + 1];
+    const char *last = argv[optind + 2];
+    char **list = NULL; int n_list = 0;
+    if (!multisample) { list = (char **)malloc(sizeof(char *)); list[0] = strdup(last); n_list = 1; }
+    else {
+        FILE *f = fopen(last, "r");
+        if (!f) { fprintf(stderr, "Can't open alignment list file.\n"); return 1; }
+        char line[4096];
+        while (fgets(line, sizeof line, f)) {
+            size_t n = strlen(line);
+            while (n && (line[n - 1] == '\n' || line[n - 1] == '\r')) line[--n] = 0;
+            if (!n) continue;
+            list = (char **)realloc(list, sizeof(char *) * (size_t)(n_list + 1));
+            list[n_list++] = strdup(line);
+        }
+        fclose(f);
+        if (!n_list) { fprintf(stderr, "No alignment files in the alignment list\n"); return 1; }
+    }
+    cfg.aln = list; cfg.n_aln = n_list;
+    mkdir(cfg.outdir, 0777);
+
+    char err[512];
+    emsar_rsh *rsh = NULL;
+    double t0 = now_s();
+    int rc = emsar_rsh_read(cfg.rsh_path, &rsh, err, sizeof err);
+    if (rc) { fprintf(stderr, "%s\n", err); return 1; }
+    if (cfg.verbose > 0) fprintf(stdout, "rsh: %d transcripts, %lld segments, fragment lengths %d-%d (%.2fs)\n", rsh->n_tx,
+                                 (long long)rsh->n_rows, rsh->frag_min, rsh->frag_max, now_s() - t0);
+
+    int n_workers = 1;
+    if (multisample) {
+        /* one worker per GPU; a probe context tells us how many devices exist without touching HIP here */
+        int avail = 0;
+        for (int d = 0; d < 64; d++) { emsar_hip_ctx *probe = NULL; if (emsar_hip_create(&probe, d) != 0) break; emsar_hip_destroy(probe); avail++; }
+        if (avail == 0) { fprintf(stderr, "%s\n", emsar_hip_strerror(EMSAR_HIP_ERR_NO_DEVICE)); return 1; }
+        n_workers = gpus > 0 && gpus < avail ? gpus : avail;
+        if (n_workers > n_list) n_workers = n_list;
+    }
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER; pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
+    int next_model = 0; double eumacut = 0.0;
+    int *status = (int *)calloc((size_t)n_list, sizeof(int));
+    emsar_em_stats *stats = (emsar_em_stats *)calloc((size_t)n_list, sizeof(emsar_em_stats));
+    double *parse_s = (double *)calloc((size_t)n_list, sizeof(double));
+    worker_arg *wa = (worker_arg *)calloc((size_t)n_workers, sizeof(worker_arg));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_workers, sizeof(pthread_t));
+    t0 = now_s();
+    for (int g = 0; g < n_workers; g++) {
+        wa[g] = (worker_arg){&cfg, rsh, multisample ? g : device, n_workers, g, &mu, &cv, &next_model, &eumacut, status, stats, parse_s};
+        if (g > 0) pthread_create(&th[g], NULL, worker_main, &wa[g]);
+    }
+    worker_main(&wa[0]);
+    for (int g = 1; g < n_workers; g++) pthread_join(th[g], NULL);
+    double wall = now_s() - t0;
+    int bad = 0;
+    for (int i = 0; i < n_list; i++) if (status[i]) bad++;
+    if (cfg.stats_json) {
+        FILE *f = fopen(cfg.stats_json, "w");
+        if (f) {
+            fprintf(f, "{\"samples\": %d, \"gpus\": %d, \"wall_s\": %.6f, \"failed\": %d, \"per_sample\": [", n_list, n_workers, wall, bad);
+            for (int i = 0; i < n_list; i++)
+                fprintf(f, "%s{\"status\": %d, \"parse_s\": %.6f, \"em_passes\": %d, \"converged\": %d, \"solve_ms\": %.4f, \"kernel_ms\": %.4f, \"loglik\": %.9g, \"bytes_per_pass\": %lld}",
+                        i ? ", " : "", status[i], parse_s[i], stats[i].iters, stats[i].converged, stats[i].solve_ms, stats[i].kernel_ms, stats[i].loglik,
+                        (long long)stats[i].bytes_per_pass);
+            fprintf(f, "]}\n");
+            fclose(f);
+        }
+    }
+    emsar_rsh_free(rsh);
+    for (int i = 0; i < n_list; i++) free(list[i]);
+    free(list); free(status); free(stats); free(parse_s); free(wa); free(th);
+    return bad ? 1 : 0;
+}

@@ -1,0 +1,263 @@
+/* rsh.c -- reader of the EMSAR .rsh text index into flat arrays.
+ *
+ * Format (written by print_rsh, /root/reference/src/emsar_functions.c:2085-2127; read by
+ * construct_rsh_from_rshfile / parse_rsh_*line, emsar_functions.c:1351-1510):
+ *     #max_tid,max_t_size,minfrag,maxfrag,readlength          readlength -1 for single-end
+ *     @<tid>\t<name>                                          one per transcript
+ *     cid\tno.tids\t...                                        heading line (anything starting with 'c' is skipped)
+ *     cid\tn\tfirst_tid\tother,tids,\tE0,E1,...,              one per segment; empty last field = no node
+ * Row (cid) order is the one scan_rshbucket produces (emsar_functions.c:2149-2191): one single-tid row per tid
+ * (present even when the transcript has no unique region), then multi-tid rows by size, first tid, list order.
+ * Where the reference keeps a pointer structure (rshbucket[size-2][first_tid] -> sorted linked list), we keep
+ * CSR plus a hash from the sorted tid multiset to the row.
+ */
+#include "emsar_host.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+/* ---------- growing line reader over zlib (reads plain text and .gz alike) ---------- */
+typedef struct { gzFile f; char *buf; size_t cap; } linereader;
+
+static int lr_open(linereader *lr, const char *path) {
+    lr->f = (path && strcmp(path, "-") != 0 && path[0]) ? gzopen(path, "rb") : gzdopen(0, "rb");
+    lr->cap = 1 << 16;
+    lr->buf = (char *)malloc(lr->cap);
+    return (lr->f && lr->buf) ? 0 : -1;
+}
+/* returns NULL at EOF; strips the trailing newline */
+static char *lr_next(linereader *lr) {
+    size_t n = 0;
+    for (;;) {
+        if (!gzgets(lr->f, lr->buf + n, (int)(lr->cap - n))) { if (n == 0) return NULL; break; }
+        n += strlen(lr->buf + n);
+        if (n && lr->buf[n - 1] == '\n') { lr->buf[--n] = 0; break; }
+        if (n + 1 < lr->cap) break;   /* EOF without newline */
+        char *nb = (char *)realloc(lr->buf, lr->cap * 2);
+        if (!nb) return NULL;
+        lr->buf = nb; lr->cap *= 2;
+    }
+    if (n && lr->buf[n - 1] == '\r') lr->buf[n - 1] = 0;
+    return lr->buf;
+}
+static void lr_close(linereader *lr) { if (lr->f) gzclose(lr->f); free(lr->buf); }
+
+/* exported to align.c */
+void *emsar_lr_open(const char *path) { linereader *lr = (linereader *)calloc(1, sizeof(*lr)); if (!lr) return NULL; if (lr_open(lr, path)) { lr_close(lr); free(lr); return NULL; } return lr; }
+char *emsar_lr_next(void *h) { return lr_next((linereader *)h); }
+void emsar_lr_close(void *h) { if (h) { lr_close((linereader *)h); free(h); } }
+
+/* ---------- name -> tid (the reference uses a character trie, stringhash.c) ---------- */
+typedef struct { uint32_t cap; int32_t *slot; char **names; } name_index;
+
+static uint64_t fnv1a(const void *p, size_t n) {
+    const unsigned char *s = (const unsigned char *)p;
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= s[i]; h *= 1099511628211ull; }
+    return h;
+}
+static name_index *ni_build(char **names, int32_t n) {
+    name_index *x = (name_index *)calloc(1, sizeof(*x));
+    if (!x) return NULL;
+    x->cap = 16; while (x->cap < (uint32_t)n * 2u + 2u) x->cap <<= 1;
+    x->slot = (int32_t *)malloc(sizeof(int32_t) * x->cap);
+    if (!x->slot) { free(x); return NULL; }
+    for (uint32_t i = 0; i < x->cap; i++) x->slot[i] = -1;
+    x->names = names;
+    for (int32_t t = 0; t < n; t++) {
+        if (!names[t]) continue;
+        uint32_t h = (uint32_t)fnv1a(names[t], strlen(names[t])) & (x->cap - 1);
+        while (x->slot[h] >= 0) h = (h + 1) & (x->cap - 1);
+        x->slot[h] = t;
+    }
+    return x;
+}
+int32_t emsar_rsh_tid_of(const emsar_rsh *r, const char *name) {
+    const name_index *x = (const name_index *)r->name_index;
+    uint32_t h = (uint32_t)fnv1a(name, strlen(name)) & (x->cap - 1);
+    while (x->slot[h] >= 0) {
+        if (strcmp(x->names[x->slot[h]], name) == 0) return x->slot[h];
+        h = (h + 1) & (x->cap - 1);
+    }
+    return -1;
+}
+
+/* ---------- sorted tid multiset -> row ---------- */
+typedef struct { uint64_t cap; int64_t *slot; } set_index;
+
+static set_index *si_build(const emsar_rsh *r) {
+    set_index *x = (set_index *)calloc(1, sizeof(*x));
+    if (!x) return NULL;
+    x->cap = 16; while (x->cap < (uint64_t)r->n_rows * 2u + 2u) x->cap <<= 1;
+    x->slot = (int64_t *)malloc(sizeof(int64_t) * x->cap);
+    if (!x->slot) { free(x); return NULL; }
+    for (uint64_t i = 0; i < x->cap; i++) x->slot[i] = -1;
+    for (int64_t c = r->n_tx; c < r->n_rows; c++) {           /* multi-tid rows only; singles are found by tid */
+        const int32_t *t = r->col_idx + r->row_ptr[c];
+        size_t n = (size_t)(r->row_ptr[c + 1] - r->row_ptr[c]);
+        uint64_t h = fnv1a(t, n * sizeof(int32_t)) & (x->cap - 1);
+        int dup = 0;
+        while (x->slot[h] >= 0) {
+            int64_t o = x->slot[h];
+            if (r->row_ptr[o + 1] - r->row_ptr[o] == n && memcmp(r->col_idx + r->row_ptr[o], t, n * sizeof(int32_t)) == 0) { dup = 1; break; }
+            h = (h + 1) & (x->cap - 1);
+        }
+        if (!dup) x->slot[h] = c;     /* a repeated segment: the reference's list walk stops at the first one too */
+    }
+    return x;
+}
+int64_t emsar_rsh_row_of(const emsar_rsh *r, const int32_t *t, int n) {
+    if (n == 1) return (t[0] >= 0 && t[0] < r->n_tx && r->has_node[t[0]]) ? t[0] : -1;   /* update_rshbucket_single, 1528-1536 */
+    if (n > r->max_t_size) return -1;                                                      /* update_rshbucket 'r', 1599 */
+    const set_index *x = (const set_index *)r->set_index;
+    uint64_t h = fnv1a(t, (size_t)n * sizeof(int32_t)) & (x->cap - 1);
+    while (x->slot[h] >= 0) {
+        int64_t o = x->slot[h];
+        if (r->row_ptr[o + 1] - r->row_ptr[o] == (uint64_t)n && memcmp(r->col_idx + r->row_ptr[o], t, (size_t)n * sizeof(int32_t)) == 0) return o;
+        h = (h + 1) & (x->cap - 1);
+    }
+    return -1;
+}
+
+/* ---------- parsing ---------- */
+typedef struct { int32_t size, tid0; int64_t seq; int32_t *tids; int32_t *euma; } mrow;
+
+static int cmp_mrow(const void *a, const void *b) {
+    const mrow *x = (const mrow *)a, *y = (const mrow *)b;
+    if (x->size != y->size) return x->size < y->size ? -1 : 1;
+    if (x->tid0 != y->tid0) return x->tid0 < y->tid0 ? -1 : 1;
+    return x->seq < y->seq ? -1 : (x->seq > y->seq);
+}
+
+/* split "a,b,c," into ints; returns count (atoi semantics like the reference) */
+static int parse_int_list(const char *s, int32_t *out, int max) {
+    int n = 0;
+    while (*s && n < max) {
+        const char *e = strchr(s, ',');
+        out[n++] = atoi(s);
+        if (!e) break;
+        s = e + 1;
+    }
+    return n;
+}
+
+#define FAIL(code, ...) do { if (err) snprintf(err, errlen, __VA_ARGS__); rc = (code); goto done; } while (0)
+
+int emsar_rsh_read(const char *path, emsar_rsh **out, char *err, size_t errlen) {
+    int rc = EMSAR_HOST_OK;
+    linereader lr = {0};
+    emsar_rsh *r = (emsar_rsh *)calloc(1, sizeof(*r));
+    mrow *multi = NULL; size_t n_multi = 0, cap_multi = 0;
+    int32_t **single = NULL;   /* EUMA vector of the single-tid node of each tid, NULL if none */
+    int have_hdr = 0;
+    *out = NULL;
+    if (!r) return EMSAR_HOST_ERR_OOM;
+    if (lr_open(&lr, path)) FAIL(EMSAR_HOST_ERR_IO, "can't open input rsh file %s", path);
+    char *line;
+    while ((line = lr_next(&lr))) {
+        if (line[0] == '#') {                                              /* parse_rsh_headerline, 1406-1430 */
+            int a[5] = {0, 0, 0, 0, -1};
+            if (sscanf(line + 1, "%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4]) < 4) FAIL(EMSAR_HOST_ERR_FORMAT, "bad rsh header line");
+            if (a[0] < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "bad max_tid in rsh header");
+            r->n_tx = a[0] + 1; r->max_t_size = a[1]; r->hdr_minfrag = a[2]; r->hdr_maxfrag = a[3]; r->hdr_readlength = a[4];
+            /* determine_fraglength_range, 2471-2475 */
+            r->frag_min = r->hdr_minfrag > r->hdr_readlength ? r->hdr_minfrag : r->hdr_readlength;
+            r->frag_max = r->hdr_maxfrag >= r->frag_min ? r->hdr_maxfrag : r->frag_min;
+            r->nfl = r->frag_max - r->frag_min + 1;
+            if (r->nfl < 1 || r->hdr_minfrag < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "bad fragment range in rsh header");
+            r->names = (char **)calloc((size_t)r->n_tx, sizeof(char *));
+            single = (int32_t **)calloc((size_t)r->n_tx, sizeof(int32_t *));
+            if (!r->names || !single) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+            have_hdr = 1;
+        } else if (line[0] == '@') {                                       /* parse_rsh_indexline, 1381-1403 */
+            if (!have_hdr) FAIL(EMSAR_HOST_ERR_FORMAT, "rsh index line before the header");
+            char *tab = strchr(line, '\t');
+            int tid = atoi(line + 1);
+            if (!tab || tid < 0 || tid >= r->n_tx) FAIL(EMSAR_HOST_ERR_FORMAT, "bad rsh index line: %.60s", line);
+            char *e = strchr(tab + 1, '\t'); if (e) *e = 0;
+            free(r->names[tid]);
+            r->names[tid] = strdup(tab + 1);
+        } else if (line[0] == 'c' || line[0] == 0) {
+            continue;                                                      /* column headings (1370) */
+        } else {                                                           /* parse_rsh_mainline, 1432-1510 */
+            if (!have_hdr) FAIL(EMSAR_HOST_ERR_FORMAT, "rsh segment line before the header");
+            char *f[5] = {line, NULL, NULL, NULL, NULL};
+            int nf = 1;
+            for (char *p = line; *p && nf < 5; p++) if (*p == '\t') { *p = 0; f[nf++] = p + 1; }
+            if (nf < 3) FAIL(EMSAR_HOST_ERR_FORMAT, "short rsh segment line");
+            int size = atoi(f[1]), tid0 = atoi(f[2]);
+            const char *others = nf > 3 ? f[3] : "", *eumas = nf > 4 ? f[4] : "";
+            if (f[4]) { char *e = strchr(f[4], '\t'); if (e) *e = 0; }
+            if (size < 1 || tid0 < 0 || tid0 >= r->n_tx) FAIL(EMSAR_HOST_ERR_FORMAT, "bad segment line (size %d tid %d)", size, tid0);
+            if (eumas[0] == 0) continue;                                   /* no EUMA -> no node (1486) */
+            int32_t *eu = (int32_t *)calloc((size_t)r->nfl, sizeof(int32_t));
+            if (!eu) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+            parse_int_list(eumas, eu, r->nfl);
+            if (size == 1) { free(single[tid0]); single[tid0] = eu; continue; }   /* rshbucket_single[tid0]=q: last wins (1488) */
+            if (n_multi == cap_multi) {
+                cap_multi = cap_multi ? cap_multi * 2 : 1024;
+                mrow *nm = (mrow *)realloc(multi, cap_multi * sizeof(mrow));
+                if (!nm) { free(eu); FAIL(EMSAR_HOST_ERR_OOM, "out of memory"); }
+                multi = nm;
+            }
+            mrow *m = &multi[n_multi];
+            m->size = size; m->tid0 = tid0; m->seq = (int64_t)n_multi; m->euma = eu;
+            m->tids = (int32_t *)malloc(sizeof(int32_t) * (size_t)size);
+            if (!m->tids) { free(eu); FAIL(EMSAR_HOST_ERR_OOM, "out of memory"); }
+            n_multi++;
+            m->tids[0] = tid0;
+            int got = parse_int_list(others, m->tids + 1, size - 1);
+            if (got != size - 1) FAIL(EMSAR_HOST_ERR_FORMAT, "segment line lists %d other tids, %d expected", got, size - 1);
+            for (int i = 1; i < size; i++) if (m->tids[i] < 0 || m->tids[i] >= r->n_tx) FAIL(EMSAR_HOST_ERR_FORMAT, "tid out of range in segment line");
+            if (size > r->max_t_size) r->max_t_size = size;
+        }
+    }
+    if (!have_hdr) FAIL(EMSAR_HOST_ERR_FORMAT, "rsh file has no header line");
+    for (int32_t t = 0; t < r->n_tx; t++) if (!r->names[t]) FAIL(EMSAR_HOST_ERR_FORMAT, "no @ line for tid %d", t);
+    /* scan order of the multi-tid nodes: size, first tid, list (= file) order */
+    qsort(multi, n_multi, sizeof(mrow), cmp_mrow);
+    r->n_rows = (int64_t)r->n_tx + (int64_t)n_multi;
+    uint64_t nnz = (uint64_t)r->n_tx;
+    for (size_t i = 0; i < n_multi; i++) nnz += (uint64_t)multi[i].size;
+    r->row_ptr = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)r->n_rows + 1));
+    r->col_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)nnz);
+    r->euma = (int32_t *)calloc((size_t)r->n_rows * (size_t)r->nfl, sizeof(int32_t));
+    r->has_node = (uint8_t *)calloc((size_t)r->n_rows, 1);
+    if (!r->row_ptr || !r->col_idx || !r->euma || !r->has_node) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+    uint64_t k = 0;
+    for (int32_t t = 0; t < r->n_tx; t++) {
+        r->row_ptr[t] = k; r->col_idx[k++] = t;
+        if (single[t]) { memcpy(r->euma + (size_t)t * (size_t)r->nfl, single[t], sizeof(int32_t) * (size_t)r->nfl); r->has_node[t] = 1; }
+    }
+    for (size_t i = 0; i < n_multi; i++) {
+        int64_t c = (int64_t)r->n_tx + (int64_t)i;
+        r->row_ptr[c] = k;
+        memcpy(r->col_idx + k, multi[i].tids, sizeof(int32_t) * (size_t)multi[i].size);
+        k += (uint64_t)multi[i].size;
+        memcpy(r->euma + (size_t)c * (size_t)r->nfl, multi[i].euma, sizeof(int32_t) * (size_t)r->nfl);
+        r->has_node[c] = 1;
+    }
+    r->row_ptr[r->n_rows] = k;
+    r->name_index = ni_build(r->names, r->n_tx);
+    r->set_index = si_build(r);
+    if (!r->name_index || !r->set_index) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+done:
+    lr_close(&lr);
+    if (single) { for (int32_t t = 0; t < r->n_tx; t++) free(single[t]); free(single); }
+    for (size_t i = 0; i < n_multi; i++) { free(multi[i].tids); free(multi[i].euma); }
+    free(multi);
+    if (rc != EMSAR_HOST_OK) { emsar_rsh_free(r); return rc; }
+    *out = r;
+    return EMSAR_HOST_OK;
+}
+
+void emsar_rsh_free(emsar_rsh *r) {
+    if (!r) return;
+    if (r->names) { for (int32_t t = 0; t < r->n_tx; t++) free(r->names[t]); free(r->names); }
+    free(r->row_ptr); free(r->col_idx); free(r->euma); free(r->has_node);
+    if (r->name_index) { free(((name_index *)r->name_index)->slot); free(r->name_index); }
+    if (r->set_index) { free(((set_index *)r->set_index)->slot); free(r->set_index); }
+    free(r);
+}

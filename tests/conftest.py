@@ -10,7 +10,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["toy5_se50", "syn300_se", "syn300_k2", "syn2k_se"]
+CASES = ["toy5_se50", "toy5_sam", "toy5_pe", "toy5_pe_sam", "syn300_se", "syn300_k2", "syn2k_se"]
 
 
 def pytest_configure(config):

@@ -50,6 +50,12 @@ def gzip_inplace(path):
     os.remove(path)
 
 
+def sam_line(rid, flag, tname, pos0, length, md, mate=""):
+    # SAM text: QNAME FLAG RNAME POS(1-based) MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL tags
+    return "%s\t%d\t%s\t%d\t255\t%dM\t%s\t0\t0\t%s\t%s\tXA:i:0\tMD:Z:%s\tNM:i:0\n" % (
+        rid, flag, tname, pos0 + 1, length, mate or "*", "A" * length, "I" * length, md)
+
+
 def run_reference(case_dir, rsh, aln, extra_opts, runs=RUNS):
     out = os.path.join(case_dir, "_out")
     for r in range(runs):
@@ -238,8 +244,114 @@ def synth_rsh_case(case_dir, seed, n_tx, minfrag, maxfrag, n_reads, opts, fam_ma
             "opts": opts, "cmd": " ".join(cmd), "true_theta_nonzero": sum(1 for x in theta if x > 0)}
 
 
+def toy5_transcripts():
+    rng = random.Random(7)
+    ex = [rand_seq(rng, 120) for _ in range(6)]
+    return [("tA", ex[0] + ex[1] + ex[2]), ("tB", ex[0] + ex[2]), ("tC", ex[3] + ex[1] + ex[4]),
+            ("tD", ex[5]), ("tE", ex[3] + ex[4] + ex[3])]
+
+
+def case_toy5_sam(case_dir):
+    """Same model as toy5_se50 but the reads come as SAM text (-S): exercises the MD:Z mismatch count,
+    the 0x10 strand bit, unaligned records and 1-based POS."""
+    rng = random.Random(17)
+    tx = toy5_transcripts()
+    L = 50
+    with open(os.path.join(case_dir, "tx.fa"), "w") as f:
+        for n, s_ in tx:
+            f.write(">%s\n%s\n" % (n, s_))
+    subprocess.run([REF_BUILD, "-q", os.path.join(case_dir, "tx.fa"), str(L), case_dir, "index"],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    occ = {}
+    for n, s_ in tx:
+        for p_ in range(len(s_) - L + 1):
+            occ.setdefault(s_[p_:p_ + L], []).append((n, p_))
+    abund = {"tA": 5.0, "tB": 40.0, "tC": 9.0, "tD": 2.0, "tE": 11.0}
+    starts = [(n, p_) for n, s_ in tx for p_ in range(len(s_) - L + 1)]
+    weights = [abund[n] for n, _ in starts]
+    seqs = dict(tx)
+    lines = ["@HD\tVN:1.0\tSO:unsorted\n"] + ["@SQ\tSN:%s\tLN:%d\n" % (n, len(s_)) for n, s_ in tx]
+    n_reads = 2500
+    for i in range(n_reads):
+        n, p_ = rng.choices(starts, weights)[0]
+        hits = occ[seqs[n][p_:p_ + L]]
+        strand_flag = 16 if i % 3 == 0 else 0                     # unstranded library: both strands count
+        for (hn, hp) in hits:
+            lines.append(sam_line("r%d" % i, strand_flag, hn, hp, L, str(L)))
+        if i % 400 == 2:                                            # worse hit: MD with one mismatch -> filtered
+            lines.append(sam_line("r%d" % i, 0, "tD", 7, L, "10A39"))
+        if i % 450 == 3:                                            # an unaligned record in between (skipped)
+            lines.append("u%d\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (i, "A" * L, "I" * L))
+    aln = os.path.join(case_dir, "reads.sam")
+    with open(aln, "w") as f:
+        f.writelines(lines)
+    cmd = run_reference(case_dir, os.path.join(case_dir, "index.rsh"), aln, ["-S"])
+    gzip_inplace(aln)
+    return {"n_reads_emitted": n_reads, "total_read_count": n_reads, "opts": ["-S"], "cmd": " ".join(cmd)}
+
+
+def revcomp(s_):
+    return s_[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def case_toy5_pe(case_dir, sam=False):
+    """Paired-end: real emsar-build --PE index (fragment lengths 150-160), pairs as default-bowtie text or SAM."""
+    rng = random.Random(27 + sam)
+    tx = toy5_transcripts()
+    L, fmin, fmax = 50, 150, 160
+    with open(os.path.join(case_dir, "tx.fa"), "w") as f:
+        for n, s_ in tx:
+            f.write(">%s\n%s\n" % (n, s_))
+    subprocess.run([REF_BUILD, "-q", "--PE", "-f", str(fmin), "-F", str(fmax), os.path.join(case_dir, "tx.fa"), str(L),
+                    case_dir, "index"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    seqs = dict(tx)
+    occ = {}
+    for n, s_ in tx:
+        for p_ in range(len(s_) - L + 1):
+            occ.setdefault(s_[p_:p_ + L], []).append((n, p_))
+    abund = {"tA": 20.0, "tB": 6.0, "tC": 9.0, "tD": 3.0, "tE": 14.0}
+    frags = [(n, p_, fl) for n, s_ in tx for fl in range(fmin, fmax + 1) for p_ in range(len(s_) - fl + 1)]
+    weights = [abund[n] * (1.0 + 0.1 * (fl - fmin)) for n, p_, fl in frags]
+    lines = ["@HD\tVN:1.0\tSO:unsorted\n"] + ["@SQ\tSN:%s\tLN:%d\n" % (n, len(s_)) for n, s_ in tx] if sam else []
+    n_reads = 2500
+    for i in range(n_reads):
+        n, p_, fl = rng.choices(frags, weights)[0]
+        m1, m2 = seqs[n][p_:p_ + L], seqs[n][p_ + fl - L:p_ + fl]
+        # every transcript where both mates occur at a distance inside the aligner's insert window
+        pairs = []
+        for (h1, q1) in occ[m1]:
+            for (h2, q2) in occ[m2]:
+                if h1 == h2 and q2 >= q1 and fmin <= q2 - q1 + L <= fmax:
+                    pairs.append((h1, q1, q2))
+        flip = (i % 2 == 1)   # the fragment came from the other strand: mate1 is the reverse read
+        for (h, q1, q2) in pairs:
+            if sam:
+                if not flip:
+                    lines.append(sam_line("p%d" % i, 0x1 | 0x2 | 0x20 | 0x40, h, q1, L, str(L), "="))
+                    lines.append(sam_line("p%d" % i, 0x1 | 0x2 | 0x10 | 0x80, h, q2, L, str(L), "="))
+                else:
+                    lines.append(sam_line("p%d" % i, 0x1 | 0x2 | 0x10 | 0x40, h, q2, L, str(L), "="))
+                    lines.append(sam_line("p%d" % i, 0x1 | 0x2 | 0x20 | 0x80, h, q1, L, str(L), "="))
+            else:
+                a = ("+", q1)
+                b = ("-", q2)
+                first, second = (a, b) if not flip else (b, a)
+                lines.append("p%d/1\t%s\t%s\t%d\t%s\t%s\t0\t\n" % (i, first[0], h, first[1], "A" * L, "I" * L))
+                lines.append("p%d/2\t%s\t%s\t%d\t%s\t%s\t0\t\n" % (i, second[0], h, second[1], "A" * L, "I" * L))
+    aln = os.path.join(case_dir, "reads.sam" if sam else "reads.bowtie")
+    with open(aln, "w") as f:
+        f.writelines(lines)
+    opts = ["-P"] + (["-S"] if sam else [])
+    cmd = run_reference(case_dir, os.path.join(case_dir, "index.rsh"), aln, opts)
+    gzip_inplace(aln)
+    return {"n_reads_emitted": n_reads, "total_read_count": None, "opts": opts, "cmd": " ".join(cmd)}
+
+
 CASES = {
     "toy5_se50": case_toy5,
+    "toy5_sam": case_toy5_sam,
+    "toy5_pe": case_toy5_pe,
+    "toy5_pe_sam": lambda d: case_toy5_pe(d, sam=True),
     "syn300_se": lambda d: synth_rsh_case(d, seed=11, n_tx=300, minfrag=40, maxfrag=44, n_reads=6000, opts=[]),
     "syn300_k2": lambda d: synth_rsh_case(d, seed=12, n_tx=300, minfrag=36, maxfrag=36, n_reads=4000,
                                           opts=["-k", "2"]),
