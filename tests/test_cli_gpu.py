@@ -1,0 +1,90 @@
+"""GPU: the C command-line driver emsar-hip end to end (C host -> C ABI -> HIP kernels -> .fpkm) against the
+reference's own output files, single-sample and -M multi-sample."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+from emsar_amd import _build
+from tests.conftest import CASES, get_fixture
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "emsar_amd", "emsar-hip")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    _build.build_all()
+    assert os.path.exists(CLI)
+
+
+def _aln(fx):
+    return glob.glob(os.path.join(fx.dir, "reads.*.gz"))[0]
+
+
+def _check_fpkm_file(fx, path):
+    got = O.read_fpkm(path)
+    ref = fx.runs[0]
+    assert got["names"] == ref["names"]
+    fx.check_fpkm_parity(got["fpkm"], "emsar-hip " + fx.case)
+    assert (got["sd"] == 0).all()                                          # documented deviation (deterministic EM)
+    assert np.abs(got["efflen"] - ref["efflen"]).max() <= 1.01e-6           # column 4: deterministic, 6 decimals
+    mask = fx.noise_mask()
+    ok = ~mask
+    assert np.all(np.abs(got["ireadcount"] - ref["ireadcount"])[ok] <= 1e-5 * np.abs(ref["ireadcount"])[ok] + 2e-3)
+    assert np.all(np.abs(got["ireadcount_int"] - ref["ireadcount_int"])[ok] <= 1)
+    assert abs(got["tpm"].sum() - 1e6) < 1.0
+    # stationarity: inferred reads = reads inside the likelihood
+    inside = fx.model.R[fx.model.E != 0].sum()
+    assert abs(got["ireadcount"].sum() - inside) <= 1e-5 * inside + 1e-2
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_single_sample(case, tmp_path):
+    fx = get_fixture(case)
+    cmd = [CLI, "-q", "-g"] + fx.meta["opts"] + ["-I", os.path.join(fx.dir, "index.rsh"), str(tmp_path), "out", _aln(fx)]
+    subprocess.run(cmd, check=True, timeout=300)
+    _check_fpkm_file(fx, str(tmp_path / "out.0.fpkm"))
+    assert open(tmp_path / "out.0.fraglength_effect").read() == open(os.path.join(fx.dir, "ref.run0.fraglength_effect")).read()
+    seg = open(tmp_path / "out.0.segments").read().splitlines()
+    ref = open(os.path.join(fx.dir, "ref.run0.segments")).read().splitlines()
+    assert len(seg) == len(ref)
+    for a, b in zip(seg[1:], ref[1:]):
+        assert a.split("\t")[:6] == b.split("\t")[:6]
+
+
+def test_multisample_list(tmp_path):
+    """-M: the three SE cases that share an option set run as one job; file i of the list -> out.i.fpkm."""
+    fxs = [get_fixture(c) for c in ("syn300_se", "syn2k_se")]
+    # samples of one job share ONE rsh in the reference; give each rsh its own job but several files per job
+    for fx in fxs:
+        lst = tmp_path / (fx.case + ".list")
+        lst.write_text("\n".join([_aln(fx)] * 3) + "\n")
+        out = tmp_path / fx.case
+        stats = tmp_path / (fx.case + ".json")
+        subprocess.run([CLI, "-q", "-M", "--gpus", "1", "--stats-json", str(stats), "-I", os.path.join(fx.dir, "index.rsh"),
+                        str(out), "ms", str(lst)], check=True, timeout=600)
+        files = sorted(glob.glob(str(out / "ms.*.fpkm")))
+        assert [os.path.basename(f) for f in files] == ["ms.0.fpkm", "ms.1.fpkm", "ms.2.fpkm"]
+        # independent samples of identical input: equal up to the summation order of the FP64 atomics
+        vals = [O.read_fpkm(f)["fpkm"] for f in files]
+        for v in vals[1:]:
+            assert np.all(np.abs(v - vals[0]) <= 1e-6 * np.abs(vals[0]) + 1.5e-6)
+        _check_fpkm_file(fx, files[0])
+        import json
+        st = json.load(open(stats))
+        assert st["samples"] == 3 and st["failed"] == 0 and all(s["converged"] == 1 for s in st["per_sample"])
+
+
+def test_cli_errors(tmp_path):
+    fx = get_fixture("toy5_se50")
+    r = subprocess.run([CLI, "-q", "-I", str(tmp_path / "nope.rsh"), str(tmp_path), "o", _aln(fx)], capture_output=True)
+    assert r.returncode != 0 and b"can't open input rsh file" in r.stderr
+    r = subprocess.run([CLI, "-q", "-s", "bogus", "-I", os.path.join(fx.dir, "index.rsh"), str(tmp_path), "o", _aln(fx)],
+                       capture_output=True)
+    assert r.returncode != 0 and b"invalid strand type" in r.stderr
+    r = subprocess.run([CLI], capture_output=True)
+    assert r.returncode != 0 and b"Usage" in r.stderr
