@@ -37,22 +37,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-
     import numpy as np
     import torch
     from emsar_amd import EmsarHip, synth
+    from emsar_amd import dist as D
     from emsar_amd.hip import LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_WINDOWED
 
+    rank, world, local_rank = D.env_rank()
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    group = D.Group("nccl", torch.device("cuda", local_rank))   # RCCL; used for the barrier and max-over-ranks only
 
     # ---- workload: one independent sample per rank ------------------------------------------------------
     cfg = dict(synth.CONFIGS[args.config])
@@ -74,8 +69,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        group.barrier()
         torch.cuda.synchronize()
 
     # ---- warmup, then exactly K timed steps -----------------------------------------------------------------
@@ -86,10 +80,7 @@ def main():
     kernel_ms = dev.run_passes(args.steps)   # K passes back to back on the library stream; returns after its sync
     barrier()
     wall = time.perf_counter() - t0
-    if dist is not None:
-        tw = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = float(tw[0]), float(tw[1])
+    wall, kernel_ms = group.max([wall, kernel_ms])
 
     # ---- sanity of what was timed: mass conservation after the last pass --------------------------------
     th = dev.get_theta()
@@ -121,9 +112,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(s, nnz)
     dev.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
     if rank == 0:
         print(json.dumps(out))
 
