@@ -26,10 +26,12 @@
 
 #include "../../include/emsar_hip.h"
 #include "layout.hpp"
+#include "layout_tiled.hpp"
 
 namespace {
 
 using emsar::Chunk;
+using emsar::Tile;
 constexpr int kPassThreads = 512;     // 8 waves per workgroup
 constexpr int kDefaultWindow = 4096;  // 2 x 32 KiB of LDS per workgroup -> 2 workgroups per CU
 constexpr int64_t kChunkEntries = 65536;
@@ -266,6 +268,196 @@ __global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_pass_tiled: one EM pass over the TILED layout (layout_tiled.hpp).  One workgroup (8 waves) per tile.
+//   phase 0  dictionary: th_w[d] = theta[tid(d)], acc_w[d] = 0, zero slots
+//   phase E  wave s owns forward slice s (512 rows, lane = 8 rows): S_r = sum th_w[off]  (LDS reads only, 16-bit
+//            byte offsets, padding reads the zero slot: no branches), w_r = R_r / S_r -> LDS
+//   phase M  backward segments: a lane walks its few segments (15 row offsets + column header each), gathers
+//            w_r from LDS into a register sum and adds it to acc_w when the column changes; tiny columns via COO
+//   phase F  non-zero dictionary slots are flushed with one global FP64 atomic each
+// HBM traffic: 2 B per forward slot + 2 B per backward slot (16/15 + padding) -- no row_ptr, no 32-bit tids.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTiledThreads = 512;
+constexpr int kTiledLdsDoubles = 2048 + 2048 + emsar::kTileRows + 8;
+
+__device__ __forceinline__ double lds_at(const double *base, unsigned byte_off) {
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+template <int N>
+__device__ __forceinline__ void sum_n16(const int4 (&q)[N], const double *th_w, double (&S)[8]) {
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const int4 t = q[j];
+        S[0] += lds_at(th_w, (unsigned)t.x & 0xFFFFu); S[1] += lds_at(th_w, (unsigned)t.x >> 16);
+        S[2] += lds_at(th_w, (unsigned)t.y & 0xFFFFu); S[3] += lds_at(th_w, (unsigned)t.y >> 16);
+        S[4] += lds_at(th_w, (unsigned)t.z & 0xFFFFu); S[5] += lds_at(th_w, (unsigned)t.z >> 16);
+        S[6] += lds_at(th_w, (unsigned)t.w & 0xFFFFu); S[7] += lds_at(th_w, (unsigned)t.w >> 16);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void fwd_short(const int4 *e, const double *th_w, double (&S)[8]) {
+    int4 q[N];
+    load_n<N>(q, e);
+    sum_n16<N>(q, th_w, S);
+}
+
+__device__ __forceinline__ void fwd_long(const int4 *e, int k, const double *th_w, double (&S)[8]) {
+    int j = 0;
+    for (; j + kSeg <= k; j += kSeg) fwd_short<kSeg>(e + (size_t)j * 64, th_w, S);
+    for (; j < k; j++) fwd_short<1>(e + (size_t)j * 64, th_w, S);
+}
+
+// one backward batch: M segments per lane, each = header int4 {col, r1..r7} + int4 {r8..r15}
+template <int M>
+__device__ __forceinline__ void bwd_batch(const int4 *b, const double *w_r, double *acc_w) {
+    int4 q[2 * M];
+    load_n<2 * M>(q, b);
+    unsigned cur = 0xFFFFFFFFu;
+    double part = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < M; sl++) {
+        const int4 a = q[2 * sl], c = q[2 * sl + 1];
+        const unsigned col = (unsigned)a.x & 0xFFFFu;
+        if (col != cur) {
+            if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
+            cur = col; part = 0.0;
+        }
+        double s0 = lds_at(w_r, (unsigned)a.x >> 16) + lds_at(w_r, (unsigned)a.y & 0xFFFFu);
+        double s1 = lds_at(w_r, (unsigned)a.y >> 16) + lds_at(w_r, (unsigned)a.z & 0xFFFFu);
+        double s2 = lds_at(w_r, (unsigned)a.z >> 16) + lds_at(w_r, (unsigned)a.w & 0xFFFFu);
+        double s3 = lds_at(w_r, (unsigned)a.w >> 16) + lds_at(w_r, (unsigned)c.x & 0xFFFFu);
+        s0 += lds_at(w_r, (unsigned)c.x >> 16) + lds_at(w_r, (unsigned)c.y & 0xFFFFu);
+        s1 += lds_at(w_r, (unsigned)c.y >> 16) + lds_at(w_r, (unsigned)c.z & 0xFFFFu);
+        s2 += lds_at(w_r, (unsigned)c.z >> 16) + lds_at(w_r, (unsigned)c.w & 0xFFFFu);
+        s3 += lds_at(w_r, (unsigned)c.w >> 16);
+        part += (s0 + s1) + (s2 + s3);
+    }
+    if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
+}
+
+template <bool WEIGHTED, int MODE>
+__global__ __launch_bounds__(kTiledThreads) void k_pass_tiled(const Tile *__restrict__ tiles, const uint16_t *__restrict__ fwd,
+                                                              const uint16_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
+                                                              const int32_t *__restrict__ far_tid,
+                                                              const int32_t *__restrict__ wgt,    // per row slot
+                                                              const double *__restrict__ rowval,  // per row slot (MODE_SCATTER)
+                                                              const double *__restrict__ theta, double *__restrict__ acc,
+                                                              double *__restrict__ ll_out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *th_w = lds;                 // [2048]
+    double *acc_w = lds + 2048;         // [2048]
+    double *w_r = lds + 4096;           // [4096 + 8]
+    __shared__ double red[kTiledThreads / 64];
+
+    const Tile T = tiles[blockIdx.x];
+    const int nd = (int)T.near_n + (int)T.far_n;
+    for (int d = threadIdx.x; d <= nd; d += kTiledThreads) {
+        double v = 0.0;
+        if (MODE != MODE_SCATTER && d < nd) {
+            int t = d < (int)T.near_n ? T.lo + d : far_tid[T.far_off + (d - (int)T.near_n)];
+            v = theta[t];
+        }
+        th_w[d] = v;
+        acc_w[d] = 0.0;
+    }
+    const int n_slots = (int)T.n_fslices * emsar::kTileSliceRows;
+    if (threadIdx.x < 8) w_r[n_slots + threadIdx.x] = 0.0;      // padding row
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double ll = 0.0;
+    // ---- E: forward slice `wave` ----
+    if (wave < (int)T.n_fslices) {
+        const int slot0 = wave * emsar::kTileSliceRows + 8 * lane;
+        double w[8];
+        if (MODE == MODE_SCATTER) {
+            const double2 *rv = reinterpret_cast<const double2 *>(rowval + (size_t)T.row_base + slot0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { double2 v = rv[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
+        } else {
+            size_t off = 0;                       // u16 units from the tile's forward base
+            for (int s = 0; s < wave; s++) off += (size_t)T.k[s] * emsar::kTileSliceRows;
+            const int k = T.k[wave];
+            const int4 *e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 2 + off) + lane;
+            double S[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            switch (k) {
+                case 2: fwd_short<2>(e, th_w, S); break;
+                case 3: fwd_short<3>(e, th_w, S); break;
+                case 4: fwd_short<4>(e, th_w, S); break;
+                case 5: fwd_short<5>(e, th_w, S); break;
+                case 6: fwd_short<6>(e, th_w, S); break;
+                case 7: fwd_short<7>(e, th_w, S); break;
+                case 8: fwd_short<8>(e, th_w, S); break;
+                default: fwd_long(e, k, th_w, S); break;
+            }
+            double r[8] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+            if (WEIGHTED) {
+                const int4 *rw = reinterpret_cast<const int4 *>(wgt + (size_t)T.row_base + slot0);
+                int4 a = rw[0], b = rw[1];
+                r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                bool live = (S[i] > 0.0) && (r[i] > 0.0);
+                w[i] = live ? r[i] / S[i] : 0.0;
+                if (MODE == MODE_EM_LL && live) ll += r[i] * log(S[i]);
+            }
+        }
+        double2 *dst = reinterpret_cast<double2 *>(w_r + slot0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) dst[i] = make_double2(w[2 * i], w[2 * i + 1]);
+    }
+    __syncthreads();
+    // ---- M: backward batches + COO ----
+    {
+        const int m = T.bseg_m;
+        const int4 *b0 = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 2) + lane;
+        for (int bt = wave; bt < (int)T.n_bbatches; bt += kTiledThreads / 64) {
+            const int4 *b = b0 + (size_t)bt * (size_t)(2 * m) * 64;
+            switch (m) {
+                case 1: bwd_batch<1>(b, w_r, acc_w); break;
+                case 2: bwd_batch<2>(b, w_r, acc_w); break;
+                case 3: bwd_batch<3>(b, w_r, acc_w); break;
+                default: bwd_batch<4>(b, w_r, acc_w); break;
+            }
+        }
+        for (unsigned q = threadIdx.x; q < T.coo_n; q += kTiledThreads) {
+            const unsigned p = coo[T.coo_off + q];
+            const double v = lds_at(w_r, p & 0xFFFFu);
+            if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + (p >> 16)), v);
+        }
+    }
+    __syncthreads();
+    // ---- F: flush the dictionary ----
+    for (int d = threadIdx.x; d < nd; d += kTiledThreads) {
+        const double v = acc_w[d];
+        if (v != 0.0) {
+            int t = d < (int)T.near_n ? T.lo + d : far_tid[T.far_off + (d - (int)T.near_n)];
+            atomic_add_f64(&acc[t], v);
+        }
+    }
+    if (MODE == MODE_EM_LL) {
+        double t = block_sum<kTiledThreads>(ll, red);
+        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
+    }
+}
+
+// likelihood terms of the folded single-tid rows: sum_t u_t log theta_t
+__global__ __launch_bounds__(256) void k_single_ll(int n, const double *__restrict__ u, const double *__restrict__ theta, double *ll_out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+        double x = theta[t], c = u[t];
+        if (c > 0.0 && x > 0.0) s += c * log(x);
+    }
+    double tot = block_sum<256>(s, red);
+    if (threadIdx.x == 0 && tot != 0.0) atomic_add_f64(ll_out, tot);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_pass_csr: the same pass on the caller's CSR (any row order), one lane per row.
 // ------------------------------------------------------------------------------------------------
 template <typename PTR, bool WEIGHTED, int MODE>
@@ -308,13 +500,14 @@ __global__ void k_fill_start(int n, const double *__restrict__ den, double *__re
 // theta_out = theta_in * acc / den ; acc <- 0 ; scal.delta = max |dtheta| / (theta_out + floor)
 // grid-stride, one atomicMax per workgroup (hundreds of same-address atomics cost ~12 ns each)
 __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
-                                                const double *__restrict__ den, double *__restrict__ th_out,
-                                                double abs_floor, Scal *scal) {
+                                                const double *__restrict__ den, const double *__restrict__ u /* folded single-tid rows, may be null */,
+                                                double *__restrict__ th_out, double abs_floor, Scal *scal) {
     __shared__ double red[4];
     double d = 0.0;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
         double a = acc[t], dn = den[t], x = th_in[t];
-        double y = dn > 0.0 ? x * a / dn : 0.0;
+        // a row {t} contributes R/theta_t to acc_t, i.e. R to theta_t*acc_t: added analytically (TILED layout)
+        double y = dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
         th_out[t] = y;
         acc[t] = 0.0;
         double dd = fabs(y - x) / (fabs(y) + abs_floor);
@@ -450,6 +643,15 @@ struct emsar_hip_ctx {
     uint64_t *d_slice_off = nullptr;
     int32_t *d_ent = nullptr;
     int64_t padded_rows = 0;
+    // TILED layout
+    emsar::TiledLayout TL;       // host copy keeps slot_row / single_* / left_row (index arrays freed after upload)
+    Tile *d_tiles = nullptr;
+    uint16_t *d_fwd = nullptr, *d_bwd = nullptr;
+    uint32_t *d_coo = nullptr;
+    int32_t *d_far = nullptr;
+    uint64_t *d_left_ptr = nullptr; int32_t *d_left_col = nullptr; int32_t *d_left_wgt = nullptr; double *d_left_val = nullptr;
+    int64_t n_left = 0, n_tiles = 0, n_slots = 0;
+    double *d_u = nullptr;       // folded single-tid rows: per-transcript weight sum
     // sample
     bool weighted = false;
     int32_t *d_wgt = nullptr;    // row weights in layout order (0 = row outside F)
@@ -463,6 +665,7 @@ struct emsar_hip_ctx {
     Scal *d_scal = nullptr;
     Scal *h_scal = nullptr;      // pinned
     int64_t bytes_formula = 0, bytes_stored = 0;
+    int64_t tl_fwd_slots = 0, tl_n_fslices = 0;
 };
 
 namespace {
@@ -478,10 +681,21 @@ namespace {
 
 inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
 
+// bytes one pass actually streams in the chosen layout: index arrays + row weights + the T-sized vectors
+inline int64_t stored_bytes(const emsar_hip_ctx *ctx) {
+    int64_t rows = ctx->layout == EMSAR_LAYOUT_WINDOWED ? ctx->padded_rows : ctx->layout == EMSAR_LAYOUT_TILED ? ctx->n_slots + ctx->n_left : ctx->n_rows;
+    return ctx->bytes_stored + (ctx->weighted ? 4 * rows : 0) + (ctx->layout == EMSAR_LAYOUT_TILED ? 40 : 32) * (int64_t)ctx->n_tx;
+}
+
 void free_structure(emsar_hip_ctx *ctx) {
     hipFree(ctx->d_row_ptr); hipFree(ctx->d_col); hipFree(ctx->d_chunks); hipFree(ctx->d_slice_off); hipFree(ctx->d_ent);
     ctx->d_row_ptr = nullptr; ctx->d_col = nullptr; ctx->d_chunks = nullptr; ctx->d_slice_off = nullptr; ctx->d_ent = nullptr;
     hipFree(ctx->d_wgt); hipFree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
+    hipFree(ctx->d_tiles); hipFree(ctx->d_fwd); hipFree(ctx->d_bwd); hipFree(ctx->d_coo); hipFree(ctx->d_far);
+    hipFree(ctx->d_left_ptr); hipFree(ctx->d_left_col); hipFree(ctx->d_left_wgt); hipFree(ctx->d_left_val); hipFree(ctx->d_u);
+    ctx->d_tiles = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_coo = nullptr; ctx->d_far = nullptr;
+    ctx->d_left_ptr = nullptr; ctx->d_left_col = nullptr; ctx->d_left_wgt = nullptr; ctx->d_left_val = nullptr; ctx->d_u = nullptr;
+    ctx->TL = emsar::TiledLayout(); ctx->n_left = ctx->n_tiles = ctx->n_slots = 0;
     hipFree(ctx->d_den); hipFree(ctx->d_acc); ctx->d_den = nullptr; ctx->d_acc = nullptr;
     for (auto &p : ctx->d_th) { hipFree(p); p = nullptr; }
     for (auto &p : ctx->d_tmp) { hipFree(p); p = nullptr; }
@@ -492,6 +706,34 @@ void free_structure(emsar_hip_ctx *ctx) {
 
 // one pass of the chosen layout.  mode: MODE_EM / MODE_EM_LL / MODE_SCATTER
 int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, double *ll_out) {
+    if (ctx->layout == EMSAR_LAYOUT_TILED) {
+        const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
+        if (ctx->n_tiles > 0) {
+            dim3 grid((unsigned)ctx->n_tiles), block(kTiledThreads);
+#define LAUNCH_T(WT, MD)                                                                                          \
+    hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, ctx->d_tiles, ctx->d_fwd, ctx->d_bwd,   \
+                       ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out)
+            if (mode == MODE_SCATTER) LAUNCH_T(false, MODE_SCATTER);
+            else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
+            else { if (mode == MODE_EM_LL) LAUNCH_T(false, MODE_EM_LL); else LAUNCH_T(false, MODE_EM); }
+#undef LAUNCH_T
+        }
+        if (ctx->n_left > 0) {   // rows too long for a tile: generic CSR kernel on the leftover
+            dim3 grid((unsigned)std::min<int64_t>((ctx->n_left + 255) / 256, 8192)), block(256);
+#define LAUNCH_L(WT, MD)                                                                                          \
+    hipLaunchKernelGGL((k_pass_csr<uint64_t, WT, MD>), grid, block, 0, ctx->stream, ctx->n_left, ctx->d_left_ptr,     \
+                       ctx->d_left_col, ctx->d_left_wgt, ctx->d_left_val, theta, acc, ll_out)
+            if (mode == MODE_SCATTER) LAUNCH_L(false, MODE_SCATTER);
+            else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_L(true, MODE_EM_LL); else LAUNCH_L(true, MODE_EM); }
+            else { if (mode == MODE_EM_LL) LAUNCH_L(false, MODE_EM_LL); else LAUNCH_L(false, MODE_EM); }
+#undef LAUNCH_L
+        }
+        if (mode == MODE_EM_LL)
+            hipLaunchKernelGGL(k_single_ll, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx,
+                               ctx->d_u, theta, ll_out);
+        HIPCHK(hipGetLastError());
+        return EMSAR_HIP_OK;
+    }
     if (ctx->layout == EMSAR_LAYOUT_WINDOWED) {
         const int W = ctx->L.window;
         const size_t lds = (size_t)W * 2 * sizeof(double);
@@ -527,13 +769,30 @@ int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_l
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot]);
     if (rc) return rc;
     hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
-                       ctx->d_den, th_out, abs_floor, ctx->d_scal);
+                       ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->d_scal);
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
 }
 
 // scatter a per-row value (original row order, host) to its columns: out[t] = sum_c m_ct val[c]
 int scatter_rows(emsar_hip_ctx *ctx, const double *val_host, double *d_out) {
+    if (ctx->layout == EMSAR_LAYOUT_TILED) {
+        const auto &L = ctx->TL;
+        std::vector<double> slot((size_t)std::max<int64_t>(ctx->n_slots, 1), 0.0), left((size_t)std::max<int64_t>(ctx->n_left, 1), 0.0);
+        std::vector<double> base((size_t)ctx->n_tx, 0.0);
+        for (int64_t i = 0; i < ctx->n_slots; i++) if (L.slot_row[(size_t)i] >= 0) slot[(size_t)i] = val_host[L.slot_row[(size_t)i]];
+        for (int64_t i = 0; i < ctx->n_left; i++) left[(size_t)i] = val_host[L.left_row[(size_t)i]];
+        for (size_t i = 0; i < L.single_row.size(); i++) base[(size_t)L.single_tid[i]] += val_host[L.single_row[i]];
+        if (!ctx->d_rowval) HIPCHK(hipMalloc(&ctx->d_rowval, slot.size() * sizeof(double)));
+        if (!ctx->d_left_val) HIPCHK(hipMalloc(&ctx->d_left_val, left.size() * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(ctx->d_rowval, slot.data(), slot.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_left_val, left.data(), left.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_out, base.data(), base.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        int rc = launch_pass(ctx, MODE_SCATTER, nullptr, d_out, nullptr);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return EMSAR_HIP_OK;
+    }
     std::vector<double> tmp;
     const double *src = val_host;
     size_t n = (size_t)ctx->n_rows;
@@ -611,18 +870,49 @@ void emsar_hip_destroy(emsar_hip_ctx *ctx) {
 int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr,
                                const int32_t *col_idx, int layout) {
     if (!ctx) return EMSAR_HIP_ERR_ARG;
-    if (layout != EMSAR_LAYOUT_AUTO && layout != EMSAR_LAYOUT_CSR && layout != EMSAR_LAYOUT_WINDOWED) return EMSAR_HIP_ERR_ARG;
+    if (layout != EMSAR_LAYOUT_AUTO && layout != EMSAR_LAYOUT_CSR && layout != EMSAR_LAYOUT_WINDOWED && layout != EMSAR_LAYOUT_TILED) return EMSAR_HIP_ERR_ARG;
     if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     free_structure(ctx);
     ctx->n_rows = n_rows; ctx->n_tx = n_tx; ctx->nnz = (int64_t)row_ptr[n_rows];
     ctx->ptr64 = (uint64_t)ctx->nnz >= (1ull << 32);
-    if (layout == EMSAR_LAYOUT_AUTO) layout = (n_rows < ((int64_t)1 << 32)) ? EMSAR_LAYOUT_WINDOWED : EMSAR_LAYOUT_CSR;
+    if (layout == EMSAR_LAYOUT_AUTO) {
+        layout = (n_rows < ((int64_t)1 << 32)) ? EMSAR_LAYOUT_TILED : EMSAR_LAYOUT_CSR;
+        if (const char *e = getenv("EMSAR_HIP_LAYOUT")) { int v = atoi(e); if (v >= 1 && v <= 3 && (v == 1 || n_rows < ((int64_t)1 << 32))) layout = v; }
+    }
     ctx->layout = layout;
     const size_t T = (size_t)n_tx;
     try {
-        if (layout == EMSAR_LAYOUT_WINDOWED) {
+        if (layout == EMSAR_LAYOUT_TILED) {
+            auto &L = ctx->TL;
+            if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L) != 0) return EMSAR_HIP_ERR_ARG;
+            ctx->n_tiles = (int64_t)L.tiles.size(); ctx->n_slots = L.n_slots(); ctx->n_left = (int64_t)L.left_row.size();
+            auto up = [&](void **dp, const void *src, size_t bytes) -> hipError_t {
+                hipError_t e = hipMalloc(dp, std::max<size_t>(bytes, 16));
+                if (e == hipSuccess && bytes) e = hipMemcpy(*dp, src, bytes, hipMemcpyHostToDevice);
+                return e;
+            };
+            HIPCHK(up((void **)&ctx->d_tiles, L.tiles.data(), L.tiles.size() * sizeof(Tile)));
+            HIPCHK(up((void **)&ctx->d_fwd, L.fwd.data(), L.fwd.size() * 2));
+            HIPCHK(up((void **)&ctx->d_bwd, L.bwd.data(), L.bwd.size() * 2));
+            HIPCHK(up((void **)&ctx->d_coo, L.coo.data(), L.coo.size() * 4));
+            HIPCHK(up((void **)&ctx->d_far, L.far_tid.data(), L.far_tid.size() * 4));
+            HIPCHK(up((void **)&ctx->d_left_ptr, L.left_ptr.data(), L.left_ptr.size() * 8));
+            HIPCHK(up((void **)&ctx->d_left_col, L.left_col.data(), L.left_col.size() * 4));
+            HIPCHK(hipMalloc(&ctx->d_u, T * 8));
+            HIPCHK(hipMemset(ctx->d_u, 0, T * 8));
+            ctx->bytes_stored = (int64_t)L.fwd.size() * 2 + (int64_t)L.bwd.size() * 2 + (int64_t)L.coo.size() * 4 + (int64_t)L.far_tid.size() * 4 +
+                                (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4 + (int64_t)L.left_ptr.size() * 8;
+            ctx->tl_fwd_slots = (int64_t)L.fwd.size(); ctx->tl_n_fslices = 0;
+            for (const Tile &t : L.tiles) ctx->tl_n_fslices += t.n_fslices;
+            std::vector<uint16_t>().swap(L.fwd); std::vector<uint16_t>().swap(L.bwd); std::vector<uint32_t>().swap(L.coo);
+            std::vector<int32_t>().swap(L.left_col);
+            const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
+#define SETLDS_T(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+            SETLDS_T(false, MODE_EM); SETLDS_T(false, MODE_EM_LL); SETLDS_T(true, MODE_EM); SETLDS_T(true, MODE_EM_LL); SETLDS_T(false, MODE_SCATTER);
+#undef SETLDS_T
+        } else if (layout == EMSAR_LAYOUT_WINDOWED) {
             const char *wenv = getenv("EMSAR_HIP_WINDOW");
             int window = wenv ? atoi(wenv) : kDefaultWindow;
             if (window < emsar::kMinBlockTids || window > 8192) window = kDefaultWindow;
@@ -687,6 +977,43 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
             if (row_weight && row_weight[r] < 0) return EMSAR_HIP_ERR_ARG;
             if (row_E && !(row_E[r] >= 0.0)) return EMSAR_HIP_ERR_ARG;  // negative or NaN
         }
+    }
+    auto weight_of = [&](int64_t r) -> int32_t {
+        int32_t x = row_weight ? row_weight[r] : 1;
+        if (row_E && row_E[r] == 0.0) x = 0;
+        return x;
+    };
+    if (ctx->layout == EMSAR_LAYOUT_TILED) {
+        const auto &L = ctx->TL;
+        hipFree(ctx->d_left_wgt); ctx->d_left_wgt = nullptr;
+        std::vector<double> u((size_t)ctx->n_tx, 0.0);
+        for (size_t i = 0; i < L.single_row.size(); i++) {
+            int32_t x = weight_of(L.single_row[i]);
+            u[(size_t)L.single_tid[i]] += (double)x;
+            if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[L.single_row[i]]);
+        }
+        HIPCHK(hipMemcpy(ctx->d_u, u.data(), u.size() * 8, hipMemcpyHostToDevice));
+        if (ctx->weighted) {
+            std::vector<int32_t> w((size_t)std::max<int64_t>(ctx->n_slots, 1), 0), wl((size_t)std::max<int64_t>(ctx->n_left, 1), 0);
+            for (int64_t i = 0; i < ctx->n_slots; i++) {
+                int64_t r = L.slot_row[(size_t)i];
+                if (r < 0) continue;
+                int32_t x = weight_of(r);
+                w[(size_t)i] = x;
+                if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[r]);
+            }
+            for (int64_t i = 0; i < ctx->n_left; i++) {
+                int64_t r = L.left_row[(size_t)i];
+                int32_t x = weight_of(r);
+                wl[(size_t)i] = x;
+                if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[r]);
+            }
+            HIPCHK(hipMalloc(&ctx->d_wgt, w.size() * 4));
+            HIPCHK(hipMemcpy(ctx->d_wgt, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc(&ctx->d_left_wgt, wl.size() * 4));
+            HIPCHK(hipMemcpy(ctx->d_left_wgt, wl.data(), wl.size() * 4, hipMemcpyHostToDevice));
+        }
+    } else if (ctx->weighted) {
         const bool win = ctx->layout == EMSAR_LAYOUT_WINDOWED;
         size_t n = win ? (size_t)ctx->padded_rows : (size_t)n_rows;
         std::vector<int32_t> w(std::max<size_t>(n, 1), 0);
@@ -833,7 +1160,7 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
         stats->kernel_ms = ms;
         stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         stats->bytes_per_pass = ctx->bytes_formula;
-        stats->stored_bytes_per_pass = ctx->bytes_stored + (ctx->weighted ? 4 * (ctx->layout == EMSAR_LAYOUT_WINDOWED ? ctx->padded_rows : ctx->n_rows) : 0) + 32 * (int64_t)n;
+        stats->stored_bytes_per_pass = stored_bytes(ctx);
     }
     return EMSAR_HIP_OK;
 }
@@ -876,6 +1203,10 @@ int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *o) {
     if (!ctx->have_structure) return EMSAR_HIP_ERR_STATE;
     memset(o, 0, sizeof(*o));
     o->n_rows = ctx->n_rows; o->nnz = ctx->nnz; o->n_tx = ctx->n_tx; o->layout = ctx->layout; o->device_id = ctx->device;
+    if (ctx->layout == EMSAR_LAYOUT_TILED) {
+        o->n_chunks = ctx->n_tiles; o->n_slices = ctx->tl_n_fslices; o->padded_entries = ctx->tl_fwd_slots;
+        o->far_entries = ctx->TL.far_entries; o->window = emsar::kTileDict;
+    }
     if (ctx->layout == EMSAR_LAYOUT_WINDOWED) {
         o->n_chunks = (int64_t)ctx->L.chunks.size();
         o->n_slices = ctx->L.n_slices();
@@ -884,7 +1215,7 @@ int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *o) {
         o->window = ctx->L.window;
     }
     o->bytes_per_pass = ctx->bytes_formula;
-    o->stored_bytes_per_pass = ctx->bytes_stored + (ctx->weighted ? 4 * (ctx->layout == EMSAR_LAYOUT_WINDOWED ? ctx->padded_rows : ctx->n_rows) : 0) + 32 * (int64_t)ctx->n_tx;
+    o->stored_bytes_per_pass = stored_bytes(ctx);
     return EMSAR_HIP_OK;
 }
 
@@ -903,6 +1234,25 @@ int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row
         info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx; info_out->layout = EMSAR_LAYOUT_WINDOWED;
         info_out->n_chunks = (int64_t)L.chunks.size(); info_out->n_slices = L.n_slices();
         info_out->padded_entries = (int64_t)L.slice_off.back(); info_out->far_entries = L.far_entries; info_out->window = window;
+    }
+    return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
+}
+
+int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
+                                     emsar_hip_info *info_out) {
+    if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
+    emsar::TiledLayout L;
+    if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L) != 0) return EMSAR_HIP_ERR_ARG;
+    int rc = emsar::check_tiled(L, row_ptr, col_idx);
+    if (info_out) {
+        memset(info_out, 0, sizeof(*info_out));
+        info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx; info_out->layout = EMSAR_LAYOUT_TILED;
+        info_out->n_chunks = (int64_t)L.tiles.size();
+        for (const Tile &t : L.tiles) info_out->n_slices += t.n_fslices;
+        info_out->padded_entries = (int64_t)L.fwd.size(); info_out->far_entries = L.far_entries; info_out->window = emsar::kTileDict;
+        info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 2 + (int64_t)L.bwd.size() * 2 + (int64_t)L.coo.size() * 4 +
+                                          (int64_t)L.far_tid.size() * 4 + (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4;
+        info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
     }
     return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
 }

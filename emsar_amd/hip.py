@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libemsar_hip.so")
 _lib = None
 
-LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_WINDOWED = 0, 1, 2
+LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_WINDOWED, LAYOUT_TILED = 0, 1, 2, 3
 
 # every symbol include/emsar_hip.h declares (tests check that the library exports exactly these)
 SYMBOLS = [
@@ -17,6 +17,7 @@ SYMBOLS = [
     "emsar_hip_upload_structure", "emsar_hip_upload_sample", "emsar_hip_solve",
     "emsar_hip_reset_theta", "emsar_hip_set_theta", "emsar_hip_get_theta", "emsar_hip_run_passes",
     "emsar_hip_ieuma", "emsar_hip_normalise", "emsar_hip_get_info", "emsar_hip_layout_selfcheck",
+    "emsar_hip_layout_selfcheck_tiled",
 ]
 
 
@@ -74,6 +75,7 @@ def load_library():
     L.emsar_hip_normalise.argtypes = [vp, f64p, f64p, C.c_int64, f64p, f64p, i32p]
     L.emsar_hip_get_info.argtypes = [vp, C.POINTER(Info)]
     L.emsar_hip_layout_selfcheck.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int32, C.c_int64, C.POINTER(Info)]
+    L.emsar_hip_layout_selfcheck_tiled.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.POINTER(Info)]
     _lib = L
     return L
 
@@ -103,6 +105,20 @@ def layout_selfcheck(n_tx, row_ptr, col_idx, window=0, chunk_entries=0):
     if rc != 0:
         raise EmsarHipError(rc, "layout_selfcheck")
     return info.as_dict()
+
+
+def layout_selfcheck_tiled(n_tx, row_ptr, col_idx):
+    """Host-only: build + decode the TILED layout (no GPU needed).  Returns its statistics."""
+    L = load_library()
+    row_ptr, col_idx = _arr(row_ptr, np.uint64), _arr(col_idx, np.int32)
+    info = Info()
+    rc = L.emsar_hip_layout_selfcheck_tiled(len(row_ptr) - 1, n_tx, _p(row_ptr, C.c_uint64), _p(col_idx, C.c_int32),
+                                            C.byref(info))
+    if rc != 0:
+        raise EmsarHipError(rc, "layout_selfcheck_tiled")
+    d = info.as_dict()
+    d["folded_single_rows"] = d.pop("bytes_per_pass")
+    return d
 
 
 class EmsarHip:

@@ -40,10 +40,13 @@ typedef enum {
 
 /* How the structure is laid out in HBM (DESIGN.md "Data layout"). */
 typedef enum {
-    EMSAR_LAYOUT_AUTO = 0,   /* WINDOWED when it applies, else CSR */
+    EMSAR_LAYOUT_AUTO = 0,   /* TILED when it applies, else CSR */
     EMSAR_LAYOUT_CSR = 1,    /* rows as given; lane-per-row walk, FP64 atomics straight to HBM/L2 */
-    EMSAR_LAYOUT_WINDOWED = 2 /* rows bucketed by smallest tid and length into 64-row column-major slices;
-                                 theta / accumulator windows staged in LDS */
+    EMSAR_LAYOUT_WINDOWED = 2, /* rows bucketed by smallest tid and length into 256-row column-major slices;
+                                 theta / accumulator windows staged in LDS, LDS atomics for the M-step */
+    EMSAR_LAYOUT_TILED = 3    /* tiles of <= 4096 rows with a chunk-local dictionary: 16-bit operands, forward index
+                                 for the E-step and transposed index for the M-step (no atomics on the hot path);
+                                 single-tid rows folded into a per-transcript count */
 } emsar_hip_layout;
 
 /* Replaces the solver knobs -e/-r/-i/-l/-n of the reference (emsar_main.c:86-91): the pattern search's
@@ -118,11 +121,11 @@ typedef struct {
     int64_t n_rows, nnz;
     int32_t n_tx;
     int32_t layout;            /* layout in use */
-    int64_t n_chunks;          /* WINDOWED: workgroup-sized work items */
-    int64_t n_slices;          /* WINDOWED: 64-row slices */
-    int64_t padded_entries;    /* WINDOWED: stored column slots incl. padding */
-    int64_t far_entries;       /* WINDOWED: entries outside their chunk's LDS window (global atomics) */
-    int32_t window;            /* WINDOWED: transcripts per LDS window */
+    int64_t n_chunks;          /* WINDOWED: chunks / TILED: tiles (one workgroup each) */
+    int64_t n_slices;          /* WINDOWED: 256-row slices / TILED: 512-row forward slices */
+    int64_t padded_entries;    /* stored forward slots incl. padding */
+    int64_t far_entries;       /* entries outside their chunk's contiguous tid range */
+    int32_t window;            /* transcripts per LDS window / dictionary */
     int32_t device_id;
     int64_t bytes_per_pass;        /* SURVEY.md 8d formula */
     int64_t stored_bytes_per_pass; /* what the layout streams */
@@ -133,6 +136,9 @@ int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *out);
  * again and check that it stores exactly the input rows.  window / chunk_entries <= 0 select the defaults. */
 int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                                int32_t window, int64_t chunk_entries, emsar_hip_info *info_out);
+/* The same for the TILED layout (forward index, transposed index, dictionaries, folded and leftover rows). */
+int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
+                                     emsar_hip_info *info_out);
 
 #ifdef __cplusplus
 }

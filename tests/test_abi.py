@@ -92,6 +92,27 @@ def test_layout_roundtrip_edge_cases(lib):
     assert info["n_slices"] == 1 and info["padded_entries"] == 256 * 700
 
 
+def test_tiled_layout_roundtrip(lib, golden):
+    m = golden.model
+    info = emsar_amd.layout_selfcheck_tiled(m.n_tx, m.row_ptr, m.col_idx)
+    assert info["folded_single_rows"] >= m.n_tx                    # every transcript has a single-tid row in an rsh
+
+
+def test_tiled_layout_roundtrip_synthetic(lib):
+    for law, xfam in (("human", 0.05), ("repeats", 0.02), ("poisson2", 0.0)):
+        m = synth.make_matrix(n_tx=6000, n_reads=60000, law=law, xfam=xfam, seed=3)
+        info = emsar_amd.layout_selfcheck_tiled(m["n_tx"], m["row_ptr"], m["col_idx"])
+        assert info["n_chunks"] >= 1
+    # rows longer than a tile can hold, duplicates inside rows, empty rows
+    rng = np.random.default_rng(1)
+    rows = [rng.integers(0, 9000, size=3000), np.array([], dtype=np.int64), rng.integers(0, 9000, size=1025),
+            np.array([7, 7, 7]), np.array([8999]), np.array([0, 8999])]
+    rp = np.zeros(len(rows) + 1, dtype=np.uint64)
+    rp[1:] = np.cumsum([len(r) for r in rows])
+    info = emsar_amd.layout_selfcheck_tiled(9000, rp, np.concatenate(rows).astype(np.int32))
+    assert info["folded_single_rows"] == 1
+
+
 def test_layout_roundtrip_golden(lib, golden):
     m = golden.model
     info = emsar_amd.layout_selfcheck(m.n_tx, m.row_ptr, m.col_idx, 256, 2048)

@@ -11,10 +11,10 @@ import pytest
 
 import oracle as O
 from emsar_amd import EmsarHip, EmsarHipError, synth
-from emsar_amd.hip import LAYOUT_CSR, LAYOUT_WINDOWED
+from emsar_amd.hip import LAYOUT_CSR, LAYOUT_TILED, LAYOUT_WINDOWED
 
 pytestmark = pytest.mark.gpu
-LAYOUTS = [LAYOUT_CSR, LAYOUT_WINDOWED]
+LAYOUTS = [LAYOUT_CSR, LAYOUT_WINDOWED, LAYOUT_TILED]
 
 
 @pytest.fixture(scope="module")
@@ -96,6 +96,37 @@ def test_known_answers_and_edge_cases(dev):
         assert (th == 0).all()
 
 
+def test_tiled_long_rows_and_folded_singles(dev):
+    """TILED: rows longer than 1024 tids go to the leftover CSR, single-tid rows are folded analytically."""
+    rng = np.random.default_rng(5)
+    n_tx = 5000
+    rows = [rng.choice(n_tx, size=1500, replace=False), rng.choice(n_tx, size=1100, replace=False)]
+    rows += [rng.integers(0, n_tx, size=int(k)) for k in rng.integers(1, 40, size=3000)]      # duplicates allowed (A2)
+    rows += [np.array([t]) for t in rng.integers(0, n_tx, size=2000)]
+    rp = np.zeros(len(rows) + 1, dtype=np.uint64)
+    rp[1:] = np.cumsum([len(r) for r in rows])
+    ci = np.concatenate(rows).astype(np.int32)
+    R = rng.integers(0, 9, size=len(rows)).astype(np.int32)
+    E = rng.random(len(rows)) + 0.1
+    E[::17] = 0.0
+    m = O.Csr(n_tx, rp, ci, R=R, E=E)
+    den = m.den()
+    want = np.where(den > 0, 1.0, 0.0)
+    for _ in range(4):
+        want, ll = m.em_step(want, den)
+    got = {}
+    for layout in LAYOUTS:
+        dev.upload_structure(n_tx, rp, ci, layout)
+        dev.upload_sample(R, E, None)
+        _, ll_dev = dev.run_passes(4, want_loglik=True)
+        got[layout] = dev.get_theta()
+        assert np.all(np.abs(got[layout] - want) <= 1e-11 * np.abs(want) + 1e-300), layout
+        assert abs(ll_dev - ll) <= 1e-10 * abs(ll)
+    if True:
+        dev.upload_structure(n_tx, rp, ci, LAYOUT_TILED)
+        np.testing.assert_allclose(dev.ieuma(E), O.Csr(n_tx, rp, ci, L=E).ieuma(), rtol=1e-12)
+
+
 def test_error_paths(dev):
     fresh = EmsarHip(0)
     with pytest.raises(EmsarHipError) as e:
@@ -133,25 +164,26 @@ def test_collapsed_and_read_level_agree(dev):
     # the reference solves the collapsed (segment) form; the read-level matrix must give the same EM
     s = synth.make_matrix(n_tx=800, n_reads=30000, law="human", xfam=0.02, seed=4)
     rp, ci, cnt = synth.collapse(s["row_ptr"], s["col_idx"])
-    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_WINDOWED)
-    dev.upload_sample(None, None, s["den"])
-    dev.run_passes(25)
-    a = dev.get_theta()
-    dev.upload_structure(s["n_tx"], rp, ci, LAYOUT_WINDOWED)
-    dev.upload_sample(cnt, None, s["den"])
-    dev.run_passes(25)
-    b = dev.get_theta()
-    assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
+    for layout in (LAYOUT_WINDOWED, LAYOUT_TILED):
+        dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], layout)
+        dev.upload_sample(None, None, s["den"])
+        dev.run_passes(25)
+        a = dev.get_theta()
+        dev.upload_structure(s["n_tx"], rp, ci, layout)
+        dev.upload_sample(cnt, None, s["den"])
+        dev.run_passes(25)
+        b = dev.get_theta()
+        assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
 
 
 def test_full_size_properties_cfg2(dev):
     """BASELINE config 2 at full size (5M reads x 80k transcripts): properties that need no oracle."""
     s = synth.make_config("cfg2", 1.0)
     n_reads, den = s["n_reads"], s["den"]
-    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_WINDOWED)
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
     dev.upload_sample(None, None, den)
     info = dev.info()
-    assert info["padded_entries"] <= 1.1 * info["nnz"]
+    assert info["padded_entries"] <= 1.15 * info["nnz"]
     prev_ll = -np.inf
     for _ in range(6):
         _, ll = dev.run_passes(1, want_loglik=True)                # ll is evaluated at the pass input
@@ -166,8 +198,9 @@ def test_full_size_properties_cfg2(dev):
     dev.reset_theta()
     dev.run_passes(3)
     a = dev.get_theta()
-    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_CSR)
-    dev.upload_sample(None, None, den)
-    dev.run_passes(3)
-    b = dev.get_theta()
-    assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
+    for layout in (LAYOUT_CSR, LAYOUT_WINDOWED):
+        dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], layout)
+        dev.upload_sample(None, None, den)
+        dev.run_passes(3)
+        b = dev.get_theta()
+        assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
