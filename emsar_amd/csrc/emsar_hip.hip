@@ -296,81 +296,136 @@ __device__ __forceinline__ void sum_n16(const int4 (&q)[N], const double *th_w, 
     }
 }
 
-template <int N>
-__device__ __forceinline__ void fwd_short(const int4 *e, const double *th_w, double (&S)[8]) {
-    int4 q[N];
-    load_n<N>(q, e);
-    sum_n16<N>(q, th_w, S);
+// one backward segment pair {col, r1..r7} {r8..r15}: gather the 15 row weights
+__device__ __forceinline__ double bwd_seg_sum(const int4 a, const int4 c, const double *w_r) {
+    double s0 = lds_at(w_r, (unsigned)a.x >> 16) + lds_at(w_r, (unsigned)a.y & 0xFFFFu);
+    double s1 = lds_at(w_r, (unsigned)a.y >> 16) + lds_at(w_r, (unsigned)a.z & 0xFFFFu);
+    double s2 = lds_at(w_r, (unsigned)a.z >> 16) + lds_at(w_r, (unsigned)a.w & 0xFFFFu);
+    double s3 = lds_at(w_r, (unsigned)a.w >> 16) + lds_at(w_r, (unsigned)c.x & 0xFFFFu);
+    s0 += lds_at(w_r, (unsigned)c.x >> 16) + lds_at(w_r, (unsigned)c.y & 0xFFFFu);
+    s1 += lds_at(w_r, (unsigned)c.y >> 16) + lds_at(w_r, (unsigned)c.z & 0xFFFFu);
+    s2 += lds_at(w_r, (unsigned)c.z >> 16) + lds_at(w_r, (unsigned)c.w & 0xFFFFu);
+    s3 += lds_at(w_r, (unsigned)c.w >> 16);
+    return (s0 + s1) + (s2 + s3);
 }
 
-__device__ __forceinline__ void fwd_long(const int4 *e, int k, const double *th_w, double (&S)[8]) {
-    int j = 0;
-    for (; j + kSeg <= k; j += kSeg) fwd_short<kSeg>(e + (size_t)j * 64, th_w, S);
-    for (; j < k; j++) fwd_short<1>(e + (size_t)j * 64, th_w, S);
-}
-
-// one backward batch: M segments per lane, each = header int4 {col, r1..r7} + int4 {r8..r15}
-template <int M>
-__device__ __forceinline__ void bwd_batch(const int4 *b, const double *w_r, double *acc_w) {
-    int4 q[2 * M];
-    load_n<2 * M>(q, b);
+// one backward batch held in registers: m (wave-uniform, 1..4) segments per lane; a lane's segments are
+// consecutive in column order, so the running sum stays in a register until the column changes
+__device__ __forceinline__ void bwd_batch_regs(const int4 (&q)[8], int m, const double *w_r, double *acc_w) {
     unsigned cur = 0xFFFFFFFFu;
     double part = 0.0;
 #pragma unroll
-    for (int sl = 0; sl < M; sl++) {
-        const int4 a = q[2 * sl], c = q[2 * sl + 1];
-        const unsigned col = (unsigned)a.x & 0xFFFFu;
-        if (col != cur) {
-            if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
-            cur = col; part = 0.0;
+    for (int sl = 0; sl < 4; sl++) {
+        if (sl < m) {
+            const int4 a = q[2 * sl], c = q[2 * sl + 1];
+            const unsigned col = (unsigned)a.x & 0xFFFFu;
+            if (col != cur) {
+                if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
+                cur = col; part = 0.0;
+            }
+            part += bwd_seg_sum(a, c, w_r);
         }
-        double s0 = lds_at(w_r, (unsigned)a.x >> 16) + lds_at(w_r, (unsigned)a.y & 0xFFFFu);
-        double s1 = lds_at(w_r, (unsigned)a.y >> 16) + lds_at(w_r, (unsigned)a.z & 0xFFFFu);
-        double s2 = lds_at(w_r, (unsigned)a.z >> 16) + lds_at(w_r, (unsigned)a.w & 0xFFFFu);
-        double s3 = lds_at(w_r, (unsigned)a.w >> 16) + lds_at(w_r, (unsigned)c.x & 0xFFFFu);
-        s0 += lds_at(w_r, (unsigned)c.x >> 16) + lds_at(w_r, (unsigned)c.y & 0xFFFFu);
-        s1 += lds_at(w_r, (unsigned)c.y >> 16) + lds_at(w_r, (unsigned)c.z & 0xFFFFu);
-        s2 += lds_at(w_r, (unsigned)c.z >> 16) + lds_at(w_r, (unsigned)c.w & 0xFFFFu);
-        s3 += lds_at(w_r, (unsigned)c.w >> 16);
-        part += (s0 + s1) + (s2 + s3);
     }
     if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
 }
 
-template <bool WEIGHTED, int MODE>
-__global__ __launch_bounds__(kTiledThreads) void k_pass_tiled(const Tile *__restrict__ tiles, const uint16_t *__restrict__ fwd,
+// E-step sums of up to 8 forward columns held in registers (n is wave-uniform)
+__device__ __forceinline__ void fwd_sum_regs(const int4 (&q)[8], int n, const double *th_w, double (&S)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j < n) {
+            const int4 t = q[j];
+            S[0] += lds_at(th_w, (unsigned)t.x & 0xFFFFu); S[1] += lds_at(th_w, (unsigned)t.x >> 16);
+            S[2] += lds_at(th_w, (unsigned)t.y & 0xFFFFu); S[3] += lds_at(th_w, (unsigned)t.y >> 16);
+            S[4] += lds_at(th_w, (unsigned)t.z & 0xFFFFu); S[5] += lds_at(th_w, (unsigned)t.z >> 16);
+            S[6] += lds_at(th_w, (unsigned)t.w & 0xFFFFu); S[7] += lds_at(th_w, (unsigned)t.w >> 16);
+        }
+    }
+}
+
+// 8 independent 16-byte loads; columns beyond n repeat column n-1 (an L1 hit) so that there is no control flow
+// between the loads and all of them are in flight together
+__device__ __forceinline__ void load8_clamped(int4 (&q)[8], const int4 *e, int n) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[j] = e[(size_t)(j < n ? j : n - 1) * 64];
+}
+
+// In-kernel stamps (diagnostic instance only, STAMP=true; never the timed kernel): s_memtime per phase and wave,
+// summed into a buffer that no other code reads.
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+template <bool WEIGHTED, int MODE, bool STAMP = false>
+__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__restrict__ tiles, const uint16_t *__restrict__ fwd,
                                                               const uint16_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
                                                               const int32_t *__restrict__ far_tid,
                                                               const int32_t *__restrict__ wgt,    // per row slot
                                                               const double *__restrict__ rowval,  // per row slot (MODE_SCATTER)
                                                               const double *__restrict__ theta, double *__restrict__ acc,
-                                                              double *__restrict__ ll_out) {
+                                                              double *__restrict__ ll_out, unsigned long long *stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *th_w = lds;                 // [2048]
     double *acc_w = lds + 2048;         // [2048]
     double *w_r = lds + 4096;           // [4096 + 8]
     __shared__ double red[kTiledThreads / 64];
+    unsigned long long ts[8];
+    if (STAMP) ts[0] = stamp_now();
 
     const Tile T = tiles[blockIdx.x];
     const int nd = (int)T.near_n + (int)T.far_n;
-    for (int d = threadIdx.x; d <= nd; d += kTiledThreads) {
-        double v = 0.0;
-        if (MODE != MODE_SCATTER && d < nd) {
-            int t = d < (int)T.near_n ? T.lo + d : far_tid[T.far_off + (d - (int)T.near_n)];
-            v = theta[t];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool has_slice = wave < (int)T.n_fslices;
+    const int m = T.bseg_m;
+    const bool has_batch = wave < (int)T.n_bbatches;
+
+    // ---- issue every global load of this wave's first work items up front: dictionary values, forward slice,
+    //      first backward batch.  They are consumed in this order, so the in-order vmcnt releases them as needed.
+    double thv[4];
+    int tid_d[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int d = threadIdx.x + i * kTiledThreads;
+        thv[i] = 0.0; tid_d[i] = -1;
+        if (d < nd) {
+            tid_d[i] = d < (int)T.near_n ? T.lo + d : far_tid[T.far_off + (d - (int)T.near_n)];
+            if (MODE != MODE_SCATTER) thv[i] = theta[tid_d[i]];
         }
-        th_w[d] = v;
-        acc_w[d] = 0.0;
+    }
+    // two register buffers of 8 loads each, used as a software pipeline: while one is consumed the next
+    // 8 KiB of the wave's stream are already in flight
+    int4 A[8], B[8];
+    const int4 *e = nullptr;
+    int k = 0;
+    if (MODE != MODE_SCATTER && has_slice) {
+        size_t off = 0;                           // u16 units from the tile's forward base
+        for (int s = 0; s < wave; s++) off += (size_t)T.k[s] * emsar::kTileSliceRows;
+        k = T.k[wave];
+        e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 2 + off) + lane;
+        load8_clamped(A, e, k < 8 ? k : 8);
+    }
+    const int4 *b0 = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 2) + lane;
+    const size_t bstride = (size_t)(2 * m) * 64;  // int4 units per backward batch
+    constexpr int NW = kTiledThreads / 64;
+
+    // ---- phase 0: dictionary into LDS ----
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int d = threadIdx.x + i * kTiledThreads;
+        if (d <= nd) { th_w[d] = thv[i]; acc_w[d] = 0.0; }
     }
     const int n_slots = (int)T.n_fslices * emsar::kTileSliceRows;
     if (threadIdx.x < 8) w_r[n_slots + threadIdx.x] = 0.0;      // padding row
+    if (STAMP) ts[1] = stamp_now();
     __syncthreads();
+    if (STAMP) ts[2] = stamp_now();
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double ll = 0.0;
     // ---- E: forward slice `wave` ----
-    if (wave < (int)T.n_fslices) {
+    if (has_slice) {
         const int slot0 = wave * emsar::kTileSliceRows + 8 * lane;
         double w[8];
         if (MODE == MODE_SCATTER) {
@@ -378,20 +433,17 @@ __global__ __launch_bounds__(kTiledThreads) void k_pass_tiled(const Tile *__rest
 #pragma unroll
             for (int i = 0; i < 4; i++) { double2 v = rv[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
         } else {
-            size_t off = 0;                       // u16 units from the tile's forward base
-            for (int s = 0; s < wave; s++) off += (size_t)T.k[s] * emsar::kTileSliceRows;
-            const int k = T.k[wave];
-            const int4 *e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 2 + off) + lane;
             double S[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            switch (k) {
-                case 2: fwd_short<2>(e, th_w, S); break;
-                case 3: fwd_short<3>(e, th_w, S); break;
-                case 4: fwd_short<4>(e, th_w, S); break;
-                case 5: fwd_short<5>(e, th_w, S); break;
-                case 6: fwd_short<6>(e, th_w, S); break;
-                case 7: fwd_short<7>(e, th_w, S); break;
-                case 8: fwd_short<8>(e, th_w, S); break;
-                default: fwd_long(e, k, th_w, S); break;
+            // columns in groups of 8: group g is summed from one buffer while group g+1 is loading into the other
+            for (int j0 = 0; j0 < k; j0 += 16) {
+                const int n0 = k - j0 < 8 ? k - j0 : 8, n1 = k - j0 - 8 < 8 ? k - j0 - 8 : 8;
+                if (n1 > 0) load8_clamped(B, e + (size_t)(j0 + 8) * 64, n1);
+                fwd_sum_regs(A, n0, th_w, S);
+                if (n1 > 0) {
+                    const int n2 = k - j0 - 16 < 8 ? k - j0 - 16 : 8;
+                    if (n2 > 0) load8_clamped(A, e + (size_t)(j0 + 16) * 64, n2);
+                    fwd_sum_regs(B, n1, th_w, S);
+                }
             }
             double r[8] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
             if (WEIGHTED) {
@@ -410,34 +462,43 @@ __global__ __launch_bounds__(kTiledThreads) void k_pass_tiled(const Tile *__rest
 #pragma unroll
         for (int i = 0; i < 4; i++) dst[i] = make_double2(w[2 * i], w[2 * i + 1]);
     }
+    // the wave's first backward batch does not depend on the E-step: get it moving before the barrier
+    if (has_batch) load8_clamped(A, b0 + (size_t)wave * bstride, 2 * m);
+    if (STAMP) ts[3] = stamp_now();
     __syncthreads();
-    // ---- M: backward batches + COO ----
-    {
-        const int m = T.bseg_m;
-        const int4 *b0 = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 2) + lane;
-        for (int bt = wave; bt < (int)T.n_bbatches; bt += kTiledThreads / 64) {
-            const int4 *b = b0 + (size_t)bt * (size_t)(2 * m) * 64;
-            switch (m) {
-                case 1: bwd_batch<1>(b, w_r, acc_w); break;
-                case 2: bwd_batch<2>(b, w_r, acc_w); break;
-                case 3: bwd_batch<3>(b, w_r, acc_w); break;
-                default: bwd_batch<4>(b, w_r, acc_w); break;
-            }
-        }
-        for (unsigned q = threadIdx.x; q < T.coo_n; q += kTiledThreads) {
-            const unsigned p = coo[T.coo_off + q];
-            const double v = lds_at(w_r, p & 0xFFFFu);
-            if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + (p >> 16)), v);
+    if (STAMP) ts[4] = stamp_now();
+    // ---- M: backward batches, double-buffered, + COO ----
+    for (int bt = wave; bt < (int)T.n_bbatches; bt += 2 * NW) {
+        const bool has1 = bt + NW < (int)T.n_bbatches, has2 = bt + 2 * NW < (int)T.n_bbatches;
+        if (has1) load8_clamped(B, b0 + (size_t)(bt + NW) * bstride, 2 * m);
+        bwd_batch_regs(A, m, w_r, acc_w);
+        if (has1) {
+            if (has2) load8_clamped(A, b0 + (size_t)(bt + 2 * NW) * bstride, 2 * m);
+            bwd_batch_regs(B, m, w_r, acc_w);
         }
     }
+    for (unsigned q = threadIdx.x; q < T.coo_n; q += kTiledThreads) {
+        const unsigned p = coo[T.coo_off + q];
+        const double v = lds_at(w_r, p & 0xFFFFu);
+        if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + (p >> 16)), v);
+    }
+    if (STAMP) ts[5] = stamp_now();
     __syncthreads();
+    if (STAMP) ts[6] = stamp_now();
     // ---- F: flush the dictionary ----
-    for (int d = threadIdx.x; d < nd; d += kTiledThreads) {
-        const double v = acc_w[d];
-        if (v != 0.0) {
-            int t = d < (int)T.near_n ? T.lo + d : far_tid[T.far_off + (d - (int)T.near_n)];
-            atomic_add_f64(&acc[t], v);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int d = threadIdx.x + i * kTiledThreads;
+        if (d < nd) {
+            const double v = acc_w[d];
+            if (v != 0.0) atomic_add_f64(&acc[tid_d[i]], v);
         }
+    }
+    if (STAMP) {
+        ts[7] = stamp_now();
+        if (lane == 0)
+            for (int i = 0; i < 7; i++) atomicAdd(&stamps[i], ts[i + 1] - ts[i]);
+        if (threadIdx.x == 0) atomicAdd(&stamps[7], 1ull);
     }
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);
@@ -1236,6 +1297,30 @@ int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row
         info_out->padded_entries = (int64_t)L.slice_off.back(); info_out->far_entries = L.far_entries; info_out->window = window;
     }
     return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
+}
+
+// Diagnostic only (not declared in the public header): one stamped pass of the TILED kernel on the current theta.
+// out[0..6] = mean cycles per wave spent in: loads issued + dictionary, barrier, E-step, barrier, M-step, barrier, flush;
+// out[7] = tiles.  The result vector theta is left untouched (acc is cleared again).
+int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
+    if (!ctx || !out || ctx->layout != EMSAR_LAYOUT_TILED || !ctx->have_sample || ctx->weighted || ctx->n_tiles == 0) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr, h[8];
+    HIPCHK(hipMalloc(&d, 64));
+    HIPCHK(hipMemsetAsync(d, 0, 64, ctx->stream));
+    const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
+    HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<false, MODE_EM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_pass_tiled<false, MODE_EM, true>), dim3((unsigned)ctx->n_tiles), dim3(kTiledThreads), lds, ctx->stream, ctx->d_tiles,
+                       ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3], d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h, d, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(d);
+    double waves = (double)h[7] * (kTiledThreads / 64);
+    for (int i = 0; i < 7; i++) out[i] = (double)h[i] / waves;
+    out[7] = (double)h[7];
+    return EMSAR_HIP_OK;
 }
 
 int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,

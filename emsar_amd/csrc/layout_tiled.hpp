@@ -19,6 +19,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -96,11 +97,10 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, co
         mintid[(size_t)r] = m;
         n_act++;
     }
-    int32_t block = kMinBlockTids;
-    {
-        int64_t want = n_act > 0 ? (16384 * (int64_t)n_tx + n_act - 1) / n_act : kMinBlockTids;
-        while (block < want && block * 2 <= 1024) block *= 2;
-    }
+    // Sort granularity in tid space.  A tile's dictionary must hold a block's tid range plus the rows' reach, so
+    // blocks stay <= 1024 tids; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
+    int32_t block = 512;
+    if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024) block = v; }
     // ---- sort: pass A by min tid, pass B by (block, length class); both stable ----
     std::vector<uint32_t> pa((size_t)n_act), perm((size_t)n_act);
     {
