@@ -277,56 +277,19 @@ __global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restri
 //   phase F  non-zero dictionary slots are flushed with one global FP64 atomic each
 // HBM traffic: 2 B per forward slot + 2 B per backward slot (16/15 + padding) -- no row_ptr, no 32-bit tids.
 // ------------------------------------------------------------------------------------------------
-constexpr int kTiledThreads = 512;
-constexpr int kTiledLdsDoubles = 2048 + 2048 + emsar::kTileRows + 8;
+constexpr int kTiledThreads = 256;                       // 4 wavefronts = 4 slices
+constexpr int kTiledWr = emsar::kTileSliceRows + 8;       // w_r of one slice + the zero padding row
+constexpr int kTiledLdsDoubles = 1024 + 1024 + emsar::kTileSlices * kTiledWr;
 
 __device__ __forceinline__ double lds_at(const double *base, unsigned byte_off) {
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-template <int N>
-__device__ __forceinline__ void sum_n16(const int4 (&q)[N], const double *th_w, double (&S)[8]) {
+// 8 independent 16-byte loads; positions beyond n repeat position n-1 (an L1 hit) so that there is no control flow
+// between the loads and all of them are in flight together
+__device__ __forceinline__ void load8_clamped(int4 (&q)[8], const int4 *e, int n) {
 #pragma unroll
-    for (int j = 0; j < N; j++) {
-        const int4 t = q[j];
-        S[0] += lds_at(th_w, (unsigned)t.x & 0xFFFFu); S[1] += lds_at(th_w, (unsigned)t.x >> 16);
-        S[2] += lds_at(th_w, (unsigned)t.y & 0xFFFFu); S[3] += lds_at(th_w, (unsigned)t.y >> 16);
-        S[4] += lds_at(th_w, (unsigned)t.z & 0xFFFFu); S[5] += lds_at(th_w, (unsigned)t.z >> 16);
-        S[6] += lds_at(th_w, (unsigned)t.w & 0xFFFFu); S[7] += lds_at(th_w, (unsigned)t.w >> 16);
-    }
-}
-
-// one backward segment pair {col, r1..r7} {r8..r15}: gather the 15 row weights
-__device__ __forceinline__ double bwd_seg_sum(const int4 a, const int4 c, const double *w_r) {
-    double s0 = lds_at(w_r, (unsigned)a.x >> 16) + lds_at(w_r, (unsigned)a.y & 0xFFFFu);
-    double s1 = lds_at(w_r, (unsigned)a.y >> 16) + lds_at(w_r, (unsigned)a.z & 0xFFFFu);
-    double s2 = lds_at(w_r, (unsigned)a.z >> 16) + lds_at(w_r, (unsigned)a.w & 0xFFFFu);
-    double s3 = lds_at(w_r, (unsigned)a.w >> 16) + lds_at(w_r, (unsigned)c.x & 0xFFFFu);
-    s0 += lds_at(w_r, (unsigned)c.x >> 16) + lds_at(w_r, (unsigned)c.y & 0xFFFFu);
-    s1 += lds_at(w_r, (unsigned)c.y >> 16) + lds_at(w_r, (unsigned)c.z & 0xFFFFu);
-    s2 += lds_at(w_r, (unsigned)c.z >> 16) + lds_at(w_r, (unsigned)c.w & 0xFFFFu);
-    s3 += lds_at(w_r, (unsigned)c.w >> 16);
-    return (s0 + s1) + (s2 + s3);
-}
-
-// one backward batch held in registers: m (wave-uniform, 1..4) segments per lane; a lane's segments are
-// consecutive in column order, so the running sum stays in a register until the column changes
-__device__ __forceinline__ void bwd_batch_regs(const int4 (&q)[8], int m, const double *w_r, double *acc_w) {
-    unsigned cur = 0xFFFFFFFFu;
-    double part = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < 4; sl++) {
-        if (sl < m) {
-            const int4 a = q[2 * sl], c = q[2 * sl + 1];
-            const unsigned col = (unsigned)a.x & 0xFFFFu;
-            if (col != cur) {
-                if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
-                cur = col; part = 0.0;
-            }
-            part += bwd_seg_sum(a, c, w_r);
-        }
-    }
-    if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
+    for (int j = 0; j < 8; j++) q[j] = e[(size_t)(j < n ? j : n - 1) * 64];
 }
 
 // E-step sums of up to 8 forward columns held in registers (n is wave-uniform)
@@ -343,15 +306,28 @@ __device__ __forceinline__ void fwd_sum_regs(const int4 (&q)[8], int n, const do
     }
 }
 
-// 8 independent 16-byte loads; columns beyond n repeat column n-1 (an L1 hit) so that there is no control flow
-// between the loads and all of them are in flight together
-__device__ __forceinline__ void load8_clamped(int4 (&q)[8], const int4 *e, int n) {
+// M-step of up to 8 backward segments of one lane ({column, 7 row offsets} each).  A lane's segments are consecutive
+// in column order: the running sum stays in a register and goes to the LDS accumulator when the column changes.
+__device__ __forceinline__ void bwd_sum_regs(const int4 (&q)[8], int n, const double *w_s, double *acc_w, unsigned &cur, double &part) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) q[j] = e[(size_t)(j < n ? j : n - 1) * 64];
+    for (int j = 0; j < 8; j++) {
+        if (j < n) {
+            const int4 t = q[j];
+            const unsigned col = (unsigned)t.x & 0xFFFFu;
+            if (col != cur) {
+                if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
+                cur = col; part = 0.0;
+            }
+            double s0 = lds_at(w_s, (unsigned)t.x >> 16) + lds_at(w_s, (unsigned)t.y & 0xFFFFu);
+            double s1 = lds_at(w_s, (unsigned)t.y >> 16) + lds_at(w_s, (unsigned)t.z & 0xFFFFu);
+            double s2 = lds_at(w_s, (unsigned)t.z >> 16) + lds_at(w_s, (unsigned)t.w & 0xFFFFu);
+            part += (s0 + s1) + (s2 + lds_at(w_s, (unsigned)t.w >> 16));
+        }
+    }
 }
 
 // In-kernel stamps (diagnostic instance only, STAMP=true; never the timed kernel): s_memtime per phase and wave,
-// summed into a buffer that no other code reads.
+// written to a slot of its own that no other code reads.
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -367,23 +343,21 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
                                                               const double *__restrict__ theta, double *__restrict__ acc,
                                                               double *__restrict__ ll_out, unsigned long long *stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *th_w = lds;                 // [2048]
-    double *acc_w = lds + 2048;         // [2048]
-    double *w_r = lds + 4096;           // [4096 + 8]
+    double *th_w = lds;                 // [1024]
+    double *acc_w = lds + 1024;         // [1024]
     __shared__ double red[kTiledThreads / 64];
-    unsigned long long ts[8];
+    unsigned long long ts[6];
     if (STAMP) ts[0] = stamp_now();
 
     const Tile T = tiles[blockIdx.x];
     const int nd = (int)T.near_n + (int)T.far_n;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool has_slice = wave < (int)T.n_fslices;
-    const int m = T.bseg_m;
-    const bool has_batch = wave < (int)T.n_bbatches;
+    const bool has_slice = wave < (int)T.n_slices;
+    double *w_s = lds + 2048 + wave * kTiledWr;     // this wave's row weights [512] + zero row
 
-    // ---- issue every global load of this wave's first work items up front: dictionary values, forward slice,
-    //      first backward batch.  They are consumed in this order, so the in-order vmcnt releases them as needed.
+    // ---- issue every global load this wave needs first, in the order of use: dictionary values, 8 forward columns,
+    //      8 backward segments.  One HBM round trip per tile; the rest of the pass touches LDS only.
     double thv[4];
     int tid_d[4];
 #pragma unroll
@@ -395,61 +369,51 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
             if (MODE != MODE_SCATTER) thv[i] = theta[tid_d[i]];
         }
     }
-    // two register buffers of 8 loads each, used as a software pipeline: while one is consumed the next
-    // 8 KiB of the wave's stream are already in flight
     int4 A[8], B[8];
-    const int4 *e = nullptr;
-    int k = 0;
-    if (MODE != MODE_SCATTER && has_slice) {
-        size_t off = 0;                           // u16 units from the tile's forward base
-        for (int s = 0; s < wave; s++) off += (size_t)T.k[s] * emsar::kTileSliceRows;
-        k = T.k[wave];
-        e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 2 + off) + lane;
-        load8_clamped(A, e, k < 8 ? k : 8);
+    const int4 *e = nullptr, *b = nullptr;
+    int k = 0, m = 0;
+    unsigned coo_base = T.coo_off, coo_n = 0;
+    if (has_slice) {
+        size_t foff = 0, boff = 0;                   // u16 units from the tile's bases
+        for (int s = 0; s < wave; s++) { foff += (size_t)T.k[s] * emsar::kTileSliceRows; boff += (size_t)T.m[s] * 512; coo_base += T.coo_n[s]; }
+        k = T.k[wave]; m = T.m[wave]; coo_n = T.coo_n[wave];
+        e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 2 + foff) + lane;
+        b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 2 + boff) + lane;
+        if (MODE != MODE_SCATTER) load8_clamped(A, e, k < 8 ? k : 8);
+        if (m > 0) load8_clamped(B, b, m < 8 ? m : 8);
     }
-    const int4 *b0 = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 2) + lane;
-    const size_t bstride = (size_t)(2 * m) * 64;  // int4 units per backward batch
-    constexpr int NW = kTiledThreads / 64;
-
-    // ---- phase 0: dictionary into LDS ----
+    // ---- phase 0: dictionary into LDS (slot nd is the zero slot) ----
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int d = threadIdx.x + i * kTiledThreads;
         if (d <= nd) { th_w[d] = thv[i]; acc_w[d] = 0.0; }
     }
-    const int n_slots = (int)T.n_fslices * emsar::kTileSliceRows;
-    if (threadIdx.x < 8) w_r[n_slots + threadIdx.x] = 0.0;      // padding row
+    if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;      // padding row of this wave's slice
     if (STAMP) ts[1] = stamp_now();
     __syncthreads();
     if (STAMP) ts[2] = stamp_now();
 
     double ll = 0.0;
-    // ---- E: forward slice `wave` ----
     if (has_slice) {
-        const int slot0 = wave * emsar::kTileSliceRows + 8 * lane;
+        // ---- E: row sums of this wave's 512 rows ----
+        const size_t slot0 = (size_t)T.row_base + (size_t)wave * emsar::kTileSliceRows + 8 * lane;
         double w[8];
         if (MODE == MODE_SCATTER) {
-            const double2 *rv = reinterpret_cast<const double2 *>(rowval + (size_t)T.row_base + slot0);
+            const double2 *rv = reinterpret_cast<const double2 *>(rowval + slot0);
 #pragma unroll
             for (int i = 0; i < 4; i++) { double2 v = rv[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
         } else {
             double S[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            // columns in groups of 8: group g is summed from one buffer while group g+1 is loading into the other
-            for (int j0 = 0; j0 < k; j0 += 16) {
-                const int n0 = k - j0 < 8 ? k - j0 : 8, n1 = k - j0 - 8 < 8 ? k - j0 - 8 : 8;
-                if (n1 > 0) load8_clamped(B, e + (size_t)(j0 + 8) * 64, n1);
+            for (int j0 = 0; j0 < k; j0 += 8) {
+                const int n0 = k - j0 < 8 ? k - j0 : 8;
+                if (j0) load8_clamped(A, e + (size_t)j0 * 64, n0);
                 fwd_sum_regs(A, n0, th_w, S);
-                if (n1 > 0) {
-                    const int n2 = k - j0 - 16 < 8 ? k - j0 - 16 : 8;
-                    if (n2 > 0) load8_clamped(A, e + (size_t)(j0 + 16) * 64, n2);
-                    fwd_sum_regs(B, n1, th_w, S);
-                }
             }
             double r[8] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
             if (WEIGHTED) {
-                const int4 *rw = reinterpret_cast<const int4 *>(wgt + (size_t)T.row_base + slot0);
-                int4 a = rw[0], b = rw[1];
-                r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+                const int4 *rw = reinterpret_cast<const int4 *>(wgt + slot0);
+                int4 x = rw[0], y = rw[1];
+                r[0] = x.x; r[1] = x.y; r[2] = x.z; r[3] = x.w; r[4] = y.x; r[5] = y.y; r[6] = y.z; r[7] = y.w;
             }
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -458,33 +422,33 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
                 if (MODE == MODE_EM_LL && live) ll += r[i] * log(S[i]);
             }
         }
-        double2 *dst = reinterpret_cast<double2 *>(w_r + slot0);
+        double2 *dst = reinterpret_cast<double2 *>(w_s + 8 * lane);
 #pragma unroll
         for (int i = 0; i < 4; i++) dst[i] = make_double2(w[2 * i], w[2 * i + 1]);
-    }
-    // the wave's first backward batch does not depend on the E-step: get it moving before the barrier
-    if (has_batch) load8_clamped(A, b0 + (size_t)wave * bstride, 2 * m);
-    if (STAMP) ts[3] = stamp_now();
-    __syncthreads();
-    if (STAMP) ts[4] = stamp_now();
-    // ---- M: backward batches, double-buffered, + COO ----
-    for (int bt = wave; bt < (int)T.n_bbatches; bt += 2 * NW) {
-        const bool has1 = bt + NW < (int)T.n_bbatches, has2 = bt + 2 * NW < (int)T.n_bbatches;
-        if (has1) load8_clamped(B, b0 + (size_t)(bt + NW) * bstride, 2 * m);
-        bwd_batch_regs(A, m, w_r, acc_w);
-        if (has1) {
-            if (has2) load8_clamped(A, b0 + (size_t)(bt + 2 * NW) * bstride, 2 * m);
-            bwd_batch_regs(B, m, w_r, acc_w);
+        // the M-step below reads rows written by OTHER lanes of this same wave: DS operations of one wave execute in
+        // order, so only the compiler has to be kept from moving the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (STAMP) ts[3] = stamp_now();
+        // ---- M: column sums over the same 512 rows, through the slice's transposed index ----
+        unsigned cur = 0xFFFFFFFFu;
+        double part = 0.0;
+        for (int j0 = 0; j0 < m; j0 += 8) {
+            const int n0 = m - j0 < 8 ? m - j0 : 8;
+            if (j0) load8_clamped(B, b + (size_t)j0 * 64, n0);
+            bwd_sum_regs(B, n0, w_s, acc_w, cur, part);
         }
-    }
-    for (unsigned q = threadIdx.x; q < T.coo_n; q += kTiledThreads) {
-        const unsigned p = coo[T.coo_off + q];
-        const double v = lds_at(w_r, p & 0xFFFFu);
-        if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + (p >> 16)), v);
-    }
-    if (STAMP) ts[5] = stamp_now();
+        if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
+        for (unsigned q = lane; q < coo_n; q += 64) {
+            const unsigned p = coo[coo_base + q];
+            const double v = lds_at(w_s, p & 0xFFFFu);
+            if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + (p >> 16)), v);
+        }
+    } else if (STAMP) ts[3] = stamp_now();
+    if (STAMP) ts[4] = stamp_now();
     __syncthreads();
-    if (STAMP) ts[6] = stamp_now();
+    if (STAMP) ts[5] = stamp_now();
     // ---- F: flush the dictionary ----
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -494,11 +458,8 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
             if (v != 0.0) atomic_add_f64(&acc[tid_d[i]], v);
         }
     }
-    if (STAMP) {
-        ts[7] = stamp_now();
-        if (lane == 0)
-            for (int i = 0; i < 7; i++) atomicAdd(&stamps[i], ts[i + 1] - ts[i]);
-        if (threadIdx.x == 0) atomicAdd(&stamps[7], 1ull);
+    if (STAMP && lane == 0) {   // [tile][wave][5 phases]: issue+dictionary, barrier, E, M, barrier
+        for (int i = 0; i < 5; i++) stamps[((size_t)blockIdx.x * (kTiledThreads / 64) + wave) * 8 + i] = ts[i + 1] - ts[i];
     }
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);
@@ -965,8 +926,7 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
             HIPCHK(hipMemset(ctx->d_u, 0, T * 8));
             ctx->bytes_stored = (int64_t)L.fwd.size() * 2 + (int64_t)L.bwd.size() * 2 + (int64_t)L.coo.size() * 4 + (int64_t)L.far_tid.size() * 4 +
                                 (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4 + (int64_t)L.left_ptr.size() * 8;
-            ctx->tl_fwd_slots = (int64_t)L.fwd.size(); ctx->tl_n_fslices = 0;
-            for (const Tile &t : L.tiles) ctx->tl_n_fslices += t.n_fslices;
+            ctx->tl_fwd_slots = (int64_t)L.fwd.size(); ctx->tl_n_fslices = L.n_fslices;
             std::vector<uint16_t>().swap(L.fwd); std::vector<uint16_t>().swap(L.bwd); std::vector<uint32_t>().swap(L.coo);
             std::vector<int32_t>().swap(L.left_col);
             const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
@@ -1305,21 +1265,26 @@ int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row
 int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
     if (!ctx || !out || ctx->layout != EMSAR_LAYOUT_TILED || !ctx->have_sample || ctx->weighted || ctx->n_tiles == 0) return EMSAR_HIP_ERR_STATE;
     HIPCHK(hipSetDevice(ctx->device));
-    unsigned long long *d = nullptr, h[8];
-    HIPCHK(hipMalloc(&d, 64));
-    HIPCHK(hipMemsetAsync(d, 0, 64, ctx->stream));
+    unsigned long long *d = nullptr;
+    const size_t nw = (size_t)ctx->n_tiles * (kTiledThreads / 64), bytes = nw * 8 * sizeof(unsigned long long);
+    HIPCHK(hipMalloc(&d, bytes));
+    HIPCHK(hipMemsetAsync(d, 0, bytes, ctx->stream));
     const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
     HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<false, MODE_EM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_pass_tiled<false, MODE_EM, true>), dim3((unsigned)ctx->n_tiles), dim3(kTiledThreads), lds, ctx->stream, ctx->d_tiles,
                        ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3], d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
-    HIPCHK(hipMemcpyAsync(h, d, 64, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> h(nw * 8);
+    HIPCHK(hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     hipFree(d);
-    double waves = (double)h[7] * (kTiledThreads / 64);
-    for (int i = 0; i < 7; i++) out[i] = (double)h[i] / waves;
-    out[7] = (double)h[7];
+    for (int i = 0; i < 7; i++) {
+        double sum = 0;
+        for (size_t w = 0; w < nw; w++) sum += (double)h[w * 8 + (size_t)i];
+        out[i] = sum / (double)nw;   // mean cycles per wave
+    }
+    out[7] = (double)ctx->n_tiles;
     return EMSAR_HIP_OK;
 }
 
@@ -1333,7 +1298,7 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
         memset(info_out, 0, sizeof(*info_out));
         info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx; info_out->layout = EMSAR_LAYOUT_TILED;
         info_out->n_chunks = (int64_t)L.tiles.size();
-        for (const Tile &t : L.tiles) info_out->n_slices += t.n_fslices;
+        info_out->n_slices = L.n_fslices;
         info_out->padded_entries = (int64_t)L.fwd.size(); info_out->far_entries = L.far_entries; info_out->window = emsar::kTileDict;
         info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 2 + (int64_t)L.bwd.size() * 2 + (int64_t)L.coo.size() * 4 +
                                           (int64_t)L.far_tid.size() * 4 + (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4;

@@ -1,20 +1,24 @@
 // layout_tiled.hpp -- host-side construction of the TILED HBM layout (pure C++, no HIP calls).
 //
-// Goal: a pass whose inner loops touch only LDS with 16-bit operands and no atomics on the hot path.
+// Goal: a pass whose inner loops touch only LDS with 16-bit operands, with no atomics on the hot path and no
+// workgroup barrier between the E-step and the M-step.
 //
 //   * rows with ONE tid never reach the kernel: they are folded into a per-transcript count vector u
 //     (acc_t += u_t / theta_t is applied analytically in k_update);
 //   * rows with 2..kMaxRowLen tids are sorted by (block(min tid), length class, min tid) like the WINDOWED
-//     layout and cut into TILES of at most 4096 rows whose distinct tids fit a 2047-entry chunk-local
-//     DICTIONARY: a contiguous range [lo, lo+near_n) plus an explicit list of far tids.  Every stored operand
-//     is the 16-bit byte offset (id*8) of a dictionary slot or of a tile-local row;
-//   * forward index (E-step, row sums): 512-row slices, column-major, lane l owns rows 8l..8l+7 so that
-//     column j of its rows is ONE int4 of eight 16-bit offsets; padding points at a zero slot (no branches);
-//   * backward index (M-step, column sums): for every dictionary column with >= 8 entries the list of its
-//     tile-local rows, cut into segments of 15 row offsets headed by the column offset (16 x u16 = two int4).
-//     Segments are assigned to lanes in contiguous column order (a lane sees few distinct columns and keeps
-//     the running sum in a register), but stored interleaved so that wave loads stay 1 KiB contiguous.
-//     Columns with < 8 entries (far tids mostly) go to a small COO list of (column, row) offset pairs;
+//     layout and cut into TILES of at most 2048 rows whose distinct tids fit a 1023-entry chunk-local
+//     DICTIONARY: the contiguous range [lo, lo+near_n) that covers most of the tile's tids plus an explicit list
+//     of far tids.  Every stored operand is the 16-bit byte offset (id*8) of a dictionary slot or of a row;
+//   * a tile has up to 4 SLICES of 512 rows; one wavefront owns one slice for the whole pass:
+//       forward index (E-step, row sums): column-major [k][512]; lane l owns rows 8l..8l+7, so column j of its
+//         rows is ONE int4 of eight 16-bit offsets; padding points at a zero slot (no branches);
+//       backward index (M-step, column sums) OF THE SAME 512 ROWS: for every dictionary column with >= 4 entries in
+//         the slice, its slice-local rows cut into segments of 7 row offsets headed by the column offset
+//         (8 x u16 = one int4).  Segments are dealt to lanes in contiguous column order (a lane keeps the running
+//         sum of a column in a register), but stored interleaved so that wave loads stay 1 KiB contiguous.
+//         Columns with < 4 entries go to a COO list of (column, row) offset pairs.
+//     Because the transposed index is per slice, the wave that computed w_r for its 512 rows is the only consumer
+//     of them: E-step and M-step need no workgroup barrier in between;
 //   * rows longer than kMaxRowLen go to a leftover CSR processed by the generic kernel.
 #pragma once
 #include <algorithm>
@@ -27,13 +31,14 @@
 
 namespace emsar {
 
-constexpr int kTileRows = 4096;        // w_r[] in LDS: 32 KiB
+constexpr int kTileSlices = 4;         // wavefronts per workgroup
 constexpr int kTileSliceRows = 512;    // 64 lanes x 8 rows
-constexpr int kTileDict = 2047;        // theta + acc windows in LDS: 2 x 16 KiB; +1 zero slot
-constexpr int kMaxRowLen = 1024;       // longer rows -> leftover CSR
-constexpr int kSegRows = 15;           // row offsets per backward segment (plus 1 header = 16 x u16)
-constexpr int kDenseMin = 8;           // columns with fewer entries use the COO list
-constexpr int64_t kTileEntries = 98304;
+constexpr int kTileRows = kTileSlices * kTileSliceRows;
+constexpr int kTileDict = 1023;        // theta + acc windows in LDS: 2 x 8 KiB; +1 zero slot
+constexpr int kMaxRowLen = 768;        // longer rows -> leftover CSR (a row must fit one dictionary)
+constexpr int kSegRows = 7;            // row offsets per backward segment (plus 1 header = 8 x u16 = one int4)
+constexpr int kDenseMin = 4;           // columns with fewer entries in a slice use the COO list
+constexpr int64_t kTileEntries = 65536;
 
 struct Tile {                // 64 bytes
     uint64_t fwd_off;        // byte offset into fwd (multiple of 1024)
@@ -41,14 +46,13 @@ struct Tile {                // 64 bytes
     uint32_t row_base;       // first row slot of the tile (multiple of 512); slot = row_base + slice*512 + 8*lane + i
     uint32_t far_off;        // index of the tile's first far tid in far_tid[]
     uint32_t coo_off;        // index of the tile's first pair in coo[]
-    uint32_t coo_n;
     int32_t lo;              // dictionary slot d < near_n  <->  tid lo + d
     uint16_t near_n, far_n;  // slot near_n + i <-> far_tid[far_off + i]; zero slot = near_n + far_n
-    uint16_t n_fslices;      // forward slices of 512 row slots (<= 8)
-    uint16_t bseg_m;         // backward segments per lane and batch
-    uint16_t n_bbatches;     // backward batches of 64*bseg_m segments
+    uint16_t n_slices;       // <= 4
     uint16_t pad0;
-    uint16_t k[8];           // padded row length of each forward slice
+    uint16_t k[4];           // padded row length of each slice's forward index
+    uint16_t m[4];           // backward segments (int4) per lane of each slice
+    uint16_t coo_n[4];       // COO pairs of each slice
 };
 static_assert(sizeof(Tile) == 64, "Tile must stay 64 bytes");
 
@@ -68,7 +72,7 @@ struct TiledLayout {
     std::vector<uint64_t> left_ptr;
     std::vector<int32_t> left_col;
     std::vector<uint32_t> left_row;
-    int64_t tiled_entries = 0, far_entries = 0, coo_entries = 0;
+    int64_t tiled_entries = 0, far_entries = 0, coo_entries = 0, n_fslices = 0;
     int64_t n_slots() const { return (int64_t)slot_row.size(); }
 };
 
@@ -98,9 +102,9 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, co
         n_act++;
     }
     // Sort granularity in tid space.  A tile's dictionary must hold a block's tid range plus the rows' reach, so
-    // blocks stay <= 1024 tids; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
+    // blocks stay small; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
     int32_t block = 512;
-    if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024) block = v; }
+    if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 512) block = v; }
     // ---- sort: pass A by min tid, pass B by (block, length class); both stable ----
     std::vector<uint32_t> pa((size_t)n_act), perm((size_t)n_act);
     {
@@ -122,137 +126,129 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, co
     // ---- tiles ----
     std::vector<int32_t> stamp((size_t)n_tx, -1), loc((size_t)n_tx, 0);
     std::vector<int32_t> distinct;
-    std::vector<uint32_t> pairs;           // (col_local << 16) | row_local, then sorted by column
-    std::vector<uint32_t> ccount;
+    std::vector<uint32_t> pairs, sorted;   // (col_local << 16) | row_in_slice
+    std::vector<uint32_t> ccount, fill;
+    std::vector<uint16_t> segs;
     int64_t i0 = 0;
     int32_t tile_id = 0;
     while (i0 < n_act) {
         // 1. how many rows fit: row cap, entry cap, distinct-tid cap
-        int64_t max_rows = kTileRows;
-        int64_t i1;
-        int32_t near_n = 0, far_n = 0, lo = 0;
-        for (;;) {
-            distinct.clear();
-            int64_t ents = 0;
-            i1 = i0;
-            while (i1 < n_act && i1 - i0 < max_rows) {
-                uint32_t r = perm[(size_t)i1];
-                uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-                if (i1 > i0 && ents + (int64_t)(e - b) > kTileEntries) break;
-                size_t before = distinct.size();
-                for (uint64_t k = b; k < e; k++) {
-                    int32_t t = col_idx[k];
-                    if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
-                }
-                if (i1 > i0 && (int64_t)distinct.size() > kTileDict) {   // undo this row
-                    for (size_t q = before; q < distinct.size(); q++) stamp[(size_t)distinct[q]] = -1;
-                    distinct.resize(before);
-                    break;
-                }
-                ents += (int64_t)(e - b);
-                i1++;
+        distinct.clear();
+        int64_t ents = 0, i1 = i0;
+        while (i1 < n_act && i1 - i0 < kTileRows) {
+            uint32_t r = perm[(size_t)i1];
+            uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+            if (i1 > i0 && ents + (int64_t)(e - b) > kTileEntries) break;
+            size_t before = distinct.size();
+            for (uint64_t k = b; k < e; k++) {
+                int32_t t = col_idx[k];
+                if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
             }
-            if ((int64_t)distinct.size() > kTileDict) return -3;       // a single row with > kTileDict tids: excluded by kMaxRowLen
-            // 2. dictionary: contiguous near range + far list, minimising the number of slots
-            std::sort(distinct.begin(), distinct.end());
-            lo = distinct[0];
-            size_t n = distinct.size(), best_c = 0;
-            int64_t best = INT64_MAX;
-            for (size_t c = 0; c < n; c++) {
-                int64_t tot = ((int64_t)distinct[c] - lo + 1) + (int64_t)(n - 1 - c);
-                if (tot <= best) { best = tot; best_c = c; }
+            if (i1 > i0 && (int64_t)distinct.size() > kTileDict) {   // undo this row, close the tile
+                for (size_t q = before; q < distinct.size(); q++) stamp[(size_t)distinct[q]] = -1;
+                distinct.resize(before);
+                break;
             }
-            if (best <= kTileDict) { near_n = distinct[best_c] - lo + 1; far_n = (int32_t)(n - 1 - best_c); break; }
-            // gaps make the range too wide: retry with fewer rows (fresh stamps)
-            tile_id++;
-            max_rows = std::max<int64_t>(1, (i1 - i0) / 2);
+            ents += (int64_t)(e - b);
+            i1++;
         }
+        if ((int64_t)distinct.size() > kTileDict) return -3;       // a single row with too many tids: excluded by kMaxRowLen
+        // 2. dictionary: the contiguous tid range [distinct[a], distinct[c]] that covers the MOST of the tile's
+        //    tids while (range length + tids outside it) still fits; the tids outside (cross-family hits on
+        //    either side) go to the explicit far list.  slots(a,c) = n + (tids missing inside the range).
+        std::sort(distinct.begin(), distinct.end());
+        const size_t n = distinct.size();
+        size_t best_a = 0, best_c = 0, a = 0;
+        for (size_t c = 0; c < n; c++) {
+            while ((int64_t)n + ((int64_t)distinct[c] - distinct[a]) - (int64_t)(c - a) > kTileDict) a++;
+            if (c == 0 || c - a > best_c - best_a) { best_a = a; best_c = c; }
+        }
+        const int32_t lo = distinct[best_a];
+        const int32_t near_n = distinct[best_c] - lo + 1;
+        const int32_t far_n = (int32_t)(n - (best_c - best_a + 1));
         Tile T;
         std::memset(&T, 0, sizeof T);
         T.lo = lo; T.near_n = (uint16_t)near_n; T.far_n = (uint16_t)far_n;
         T.far_off = (uint32_t)out.far_tid.size();
         for (size_t q = 0; q < distinct.size(); q++) {
             int32_t t = distinct[q];
-            if (t - lo < near_n) loc[(size_t)t] = t - lo;
+            if (t >= lo && t - lo < near_n) loc[(size_t)t] = t - lo;
             else { loc[(size_t)t] = near_n + (int32_t)(out.far_tid.size() - T.far_off); out.far_tid.push_back(t); }
         }
-        const uint16_t zero_off = (uint16_t)((near_n + far_n) * 8);
+        const int nd = near_n + far_n;
+        const uint16_t zero_off = (uint16_t)(nd * 8);
+        const uint16_t pad_row_off = (uint16_t)(kTileSliceRows * 8);   // w_r[512] of every slice = 0
         const int64_t nrow = i1 - i0;
-        T.n_fslices = (uint16_t)((nrow + kTileSliceRows - 1) / kTileSliceRows);
+        T.n_slices = (uint16_t)((nrow + kTileSliceRows - 1) / kTileSliceRows);
         T.row_base = (uint32_t)out.slot_row.size();
-        const uint16_t pad_row_off = (uint16_t)(T.n_fslices * kTileSliceRows * 8);   // w_r[n_slots] = 0
-        out.slot_row.resize(out.slot_row.size() + (size_t)T.n_fslices * kTileSliceRows, -1);
-        // 3. forward slices
+        out.slot_row.resize(out.slot_row.size() + (size_t)T.n_slices * kTileSliceRows, -1);
         T.fwd_off = (uint64_t)out.fwd.size() * 2;
-        pairs.clear();
-        for (int s = 0; s < T.n_fslices; s++) {
-            int64_t a = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a + kTileSliceRows);
+        T.bwd_off = (uint64_t)out.bwd.size() * 2;
+        T.coo_off = (uint32_t)out.coo.size();
+        out.n_fslices += T.n_slices;
+        // 3. forward slices (all of them first: the tile's forward block is contiguous)
+        for (int s = 0; s < T.n_slices; s++) {
+            int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
             int64_t k = 0;
-            for (int64_t i = a; i < bnd; i++) { uint32_t r = perm[(size_t)i]; k = std::max<int64_t>(k, (int64_t)(row_ptr[r + 1] - row_ptr[r])); }
+            for (int64_t i = a0; i < bnd; i++) { uint32_t r = perm[(size_t)i]; k = std::max<int64_t>(k, (int64_t)(row_ptr[r + 1] - row_ptr[r])); }
             T.k[s] = (uint16_t)k;
             size_t base = out.fwd.size();
             out.fwd.resize(base + (size_t)k * kTileSliceRows, zero_off);
-            for (int64_t i = a; i < bnd; i++) {
+            for (int64_t i = a0; i < bnd; i++) {
                 uint32_t r = perm[(size_t)i];
-                uint32_t rl = (uint32_t)(i - i0);                 // tile-local row slot
-                out.slot_row[(size_t)T.row_base + rl] = (int64_t)r;
-                uint32_t in_slice = rl % kTileSliceRows;
+                uint32_t in_slice = (uint32_t)(i - a0);
+                out.slot_row[(size_t)T.row_base + (size_t)s * kTileSliceRows + in_slice] = (int64_t)r;
                 uint64_t b = row_ptr[r], e = row_ptr[r + 1];
                 for (uint64_t q = b; q < e; q++) {
                     int32_t d = loc[(size_t)col_idx[q]];
                     out.fwd[base + (size_t)(q - b) * kTileSliceRows + in_slice] = (uint16_t)(d * 8);
-                    pairs.push_back(((uint32_t)d << 16) | rl);
                     if (d >= near_n) out.far_entries++;
                 }
                 out.tiled_entries += (int64_t)(e - b);
             }
         }
-        // 4. backward: counting sort of the pairs by column
-        const int nd = near_n + far_n;
-        ccount.assign((size_t)nd + 1, 0);
-        for (uint32_t p : pairs) ccount[(p >> 16) + 1]++;
-        for (int d = 0; d < nd; d++) ccount[(size_t)d + 1] += ccount[(size_t)d];
-        std::vector<uint32_t> sorted(pairs.size());
-        {
-            std::vector<uint32_t> fill(ccount.begin(), ccount.end() - 1);
+        // 4. backward index of each slice: its (column, row) pairs sorted by column
+        for (int s = 0; s < T.n_slices; s++) {
+            int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
+            pairs.clear();
+            for (int64_t i = a0; i < bnd; i++) {
+                uint32_t r = perm[(size_t)i];
+                uint32_t in_slice = (uint32_t)(i - a0);
+                for (uint64_t q = row_ptr[r]; q < row_ptr[r + 1]; q++) pairs.push_back(((uint32_t)loc[(size_t)col_idx[q]] << 16) | in_slice);
+            }
+            ccount.assign((size_t)nd + 1, 0);
+            for (uint32_t p : pairs) ccount[(p >> 16) + 1]++;
+            for (int d = 0; d < nd; d++) ccount[(size_t)d + 1] += ccount[(size_t)d];
+            sorted.resize(pairs.size());
+            fill.assign(ccount.begin(), ccount.end() - 1);
             for (uint32_t p : pairs) sorted[fill[p >> 16]++] = p;
-        }
-        T.coo_off = (uint32_t)out.coo.size();
-        std::vector<uint16_t> segs;                                    // logical segments, 16 x u16 each
-        for (int d = 0; d < nd; d++) {
-            uint32_t b = ccount[(size_t)d], e = ccount[(size_t)d + 1];
-            if (e - b < (uint32_t)kDenseMin) {
-                for (uint32_t q = b; q < e; q++) out.coo.push_back(((uint32_t)(d * 8) << 16) | (uint32_t)((sorted[q] & 0xFFFF) * 8));
-                out.coo_entries += e - b;
-                continue;
-            }
-            for (uint32_t q = b; q < e; q += kSegRows) {
-                segs.push_back((uint16_t)(d * 8));
-                for (uint32_t j = 0; j < (uint32_t)kSegRows; j++)
-                    segs.push_back(q + j < e ? (uint16_t)((sorted[q + j] & 0xFFFF) * 8) : pad_row_off);
-            }
-        }
-        T.coo_n = (uint32_t)out.coo.size() - T.coo_off;
-        const int64_t nseg = (int64_t)segs.size() / 16;
-        int m = (int)std::min<int64_t>(4, std::max<int64_t>(1, (nseg + 511) / 512));
-        int64_t per_batch = 64 * (int64_t)m;
-        int64_t nb = (nseg + per_batch - 1) / per_batch;
-        T.bseg_m = (uint16_t)m; T.n_bbatches = (uint16_t)nb;
-        T.bwd_off = (uint64_t)out.bwd.size() * 2;
-        {
-            size_t base = out.bwd.size();
-            out.bwd.resize(base + (size_t)nb * (size_t)per_batch * 16, pad_row_off);
-            // default-fill headers of unused segments with the zero column
-            for (int64_t g = 0; g < nb * per_batch; g++) {
-                int64_t bt = g / per_batch, lane = (g % per_batch) / m, slot = g % m;
-                // unit u = slot*2 + h ; u16 index of (batch, unit, lane, word w) = ((bt*(2m) + u)*64 + lane)*8 + w
-                size_t u0 = base + (size_t)(((bt * (2 * m) + slot * 2 + 0) * 64 + lane) * 8);
-                size_t u1 = base + (size_t)(((bt * (2 * m) + slot * 2 + 1) * 64 + lane) * 8);
-                if (g < nseg) {
-                    for (int w = 0; w < 8; w++) { out.bwd[u0 + (size_t)w] = segs[(size_t)g * 16 + (size_t)w]; out.bwd[u1 + (size_t)w] = segs[(size_t)g * 16 + 8 + (size_t)w]; }
-                } else {
-                    out.bwd[u0] = zero_off;
+            segs.clear();
+            size_t coo_before = out.coo.size();
+            for (int d = 0; d < nd; d++) {
+                uint32_t b = ccount[(size_t)d], e = ccount[(size_t)d + 1];
+                if (e - b < (uint32_t)kDenseMin) {
+                    for (uint32_t q = b; q < e; q++) out.coo.push_back(((uint32_t)(d * 8) << 16) | (uint32_t)((sorted[q] & 0xFFFF) * 8));
+                    continue;
                 }
+                for (uint32_t q = b; q < e; q += kSegRows) {
+                    segs.push_back((uint16_t)(d * 8));
+                    for (uint32_t j = 0; j < (uint32_t)kSegRows; j++)
+                        segs.push_back(q + j < e ? (uint16_t)((sorted[q + j] & 0xFFFF) * 8) : pad_row_off);
+                }
+            }
+            T.coo_n[s] = (uint16_t)(out.coo.size() - coo_before);
+            out.coo_entries += T.coo_n[s];
+            const int64_t nseg = (int64_t)segs.size() / 8;
+            const int m = (int)((nseg + 63) / 64);
+            T.m[s] = (uint16_t)m;
+            size_t base = out.bwd.size();
+            out.bwd.resize(base + (size_t)m * 64 * 8, pad_row_off);
+            for (int64_t g = 0; g < (int64_t)m * 64; g++) {
+                // logical segment g -> lane g / m, unit g % m ; physical int4 index (unit*64 + lane)
+                int64_t lane = g / m, unit = g % m;
+                size_t u0 = base + (size_t)((unit * 64 + lane) * 8);
+                if (g < nseg) for (int w = 0; w < 8; w++) out.bwd[u0 + (size_t)w] = segs[(size_t)g * 8 + (size_t)w];
+                else out.bwd[u0] = zero_off;      // unused segment: zero column, padding rows
             }
         }
         out.tiles.push_back(T);
@@ -260,7 +256,13 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, co
         tile_id++;
         i0 = i1;
     }
-    // 1 KiB alignment of every tile's sections holds by construction: fwd slices are k*512*2 B, bwd batches m*2 KiB
+    // Largest tiles first: they start while the grid is full, the small ones fill the tail.
+    auto work = [](const Tile &t) {
+        int64_t w = 0;
+        for (int s = 0; s < t.n_slices; s++) w += (int64_t)t.k[s] * kTileSliceRows + (int64_t)t.m[s] * 64 * 8 + t.coo_n[s] * 2;
+        return w;
+    };
+    std::stable_sort(out.tiles.begin(), out.tiles.end(), [&](const Tile &a, const Tile &b) { return work(a) > work(b); });
     return 0;
 }
 
@@ -282,21 +284,20 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
     std::vector<uint32_t> pf, pb;
     for (const Tile &T : L.tiles) {
         const int nd = T.near_n + T.far_n;
-        if (nd > kTileDict || T.n_fslices > 8 || T.row_base % kTileSliceRows) return -3;
+        if (nd > kTileDict || T.n_slices > kTileSlices || T.row_base % kTileSliceRows) return -3;
         auto tid_of = [&](int d) { return d < T.near_n ? T.lo + d : L.far_tid[(size_t)T.far_off + (size_t)(d - T.near_n)]; };
-        pf.clear(); pb.clear();
-        size_t off = (size_t)(T.fwd_off / 2);
-        for (int s = 0; s < T.n_fslices; s++) {
+        size_t foff = (size_t)(T.fwd_off / 2), boff = (size_t)(T.bwd_off / 2), coff = T.coo_off;
+        for (int s = 0; s < T.n_slices; s++) {
+            pf.clear(); pb.clear();
             for (int i = 0; i < kTileSliceRows; i++) {
-                uint32_t rl = (uint32_t)(s * kTileSliceRows + i);
-                int64_t r = L.slot_row[(size_t)T.row_base + rl];
+                int64_t r = L.slot_row[(size_t)T.row_base + (size_t)s * kTileSliceRows + (size_t)i];
                 a.clear();
                 for (int j = 0; j < T.k[s]; j++) {
-                    int d = L.fwd[off + (size_t)j * kTileSliceRows + (size_t)i] / 8;
+                    int d = L.fwd[foff + (size_t)j * kTileSliceRows + (size_t)i] / 8;
                     if (d > nd) return -4;
                     if (d == nd) continue;                        // zero slot = padding
                     a.push_back(tid_of(d));
-                    pf.push_back(((uint32_t)d << 16) | rl);
+                    pf.push_back(((uint32_t)d << 16) | (uint32_t)i);
                 }
                 if (r < 0) { if (!a.empty()) return -5; continue; }
                 if (seen[(size_t)r]) return -6;
@@ -304,29 +305,28 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
                 b.assign(col_idx + row_ptr[r], col_idx + row_ptr[r + 1]);
                 if (a != b) return -7;
             }
-            off += (size_t)T.k[s] * kTileSliceRows;
-        }
-        const int m = T.bseg_m;
-        size_t base = (size_t)(T.bwd_off / 2);
-        const uint32_t pad_row = (uint32_t)T.n_fslices * kTileSliceRows;
-        for (int64_t g = 0; g < (int64_t)T.n_bbatches * 64 * m; g++) {
-            int64_t bt = g / (64 * m), lane = (g % (64 * m)) / m, slot = g % m;
-            size_t u0 = base + (size_t)(((bt * (2 * m) + slot * 2 + 0) * 64 + lane) * 8);
-            size_t u1 = base + (size_t)(((bt * (2 * m) + slot * 2 + 1) * 64 + lane) * 8);
-            uint32_t d = L.bwd[u0] / 8u;
-            for (int w = 1; w < 16; w++) {
-                uint32_t rl = (w < 8 ? L.bwd[u0 + (size_t)w] : L.bwd[u1 + (size_t)(w - 8)]) / 8u;
-                if (rl == pad_row) continue;
-                if (rl > pad_row || d >= (uint32_t)nd) return -8;
-                pb.push_back((d << 16) | rl);
+            foff += (size_t)T.k[s] * kTileSliceRows;
+            const int m = T.m[s];
+            for (int64_t g = 0; g < (int64_t)m * 64; g++) {
+                int64_t lane = g / m, unit = g % m;
+                size_t u0 = boff + (size_t)((unit * 64 + lane) * 8);
+                uint32_t d = L.bwd[u0] / 8u;
+                for (int w = 1; w < 8; w++) {
+                    uint32_t rl = L.bwd[u0 + (size_t)w] / 8u;
+                    if (rl == (uint32_t)kTileSliceRows) continue;
+                    if (rl > (uint32_t)kTileSliceRows || d >= (uint32_t)nd) return -8;
+                    pb.push_back((d << 16) | rl);
+                }
             }
+            boff += (size_t)m * 64 * 8;
+            for (uint32_t q = 0; q < T.coo_n[s]; q++) {
+                uint32_t p = L.coo[coff + q];
+                pb.push_back((((p >> 16) / 8u) << 16) | ((p & 0xFFFF) / 8u));
+            }
+            coff += T.coo_n[s];
+            std::sort(pf.begin(), pf.end()); std::sort(pb.begin(), pb.end());
+            if (pf != pb) return -9;                                // the backward index is the transpose of the forward one
         }
-        for (uint32_t q = 0; q < T.coo_n; q++) {
-            uint32_t p = L.coo[(size_t)T.coo_off + q];
-            pb.push_back((((p >> 16) / 8u) << 16) | ((p & 0xFFFF) / 8u));
-        }
-        std::sort(pf.begin(), pf.end()); std::sort(pb.begin(), pb.end());
-        if (pf != pb) return -9;                                    // the backward index is the transpose of the forward one
     }
     for (int64_t r = 0; r < L.n_rows; r++)
         if (!seen[(size_t)r] && row_ptr[r + 1] != row_ptr[r]) return -10;

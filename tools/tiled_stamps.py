@@ -13,8 +13,8 @@ dev.run_passes(3)
 out = (C.c_double * 8)()
 dev._L.emsar_hip_debug_tiled_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 rc = dev._L.emsar_hip_debug_tiled_stamps(dev._h, out)
-names = ["issue loads + dictionary", "barrier 1", "E-step", "barrier 2", "M-step", "barrier 3", "flush"]
-tot = sum(out[i] for i in range(7))
+names = ["issue loads + dictionary", "barrier 1", "E-step", "M-step", "barrier 2"]
+tot = sum(out[i] for i in range(5))
 print("rc", rc, "tiles", out[7], "mean cycles per wave", tot)
 for i, n in enumerate(names):
     print("%-26s %10.0f  %5.1f%%" % (n, out[i], 100 * out[i] / tot))
