@@ -374,11 +374,18 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     int k = 0, m = 0;
     unsigned coo_base = T.coo_off, coo_n = 0;
     if (has_slice) {
-        size_t foff = 0, boff = 0;                   // u16 units from the tile's bases
-        for (int s = 0; s < wave; s++) { foff += (size_t)T.k[s] * emsar::kTileSliceRows; boff += (size_t)T.m[s] * 512; coo_base += T.coo_n[s]; }
-        k = T.k[wave]; m = T.m[wave]; coo_n = T.coo_n[wave];
-        e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 2 + foff) + lane;
-        b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 2 + boff) + lane;
+        unsigned foff = 0, boff = 0;                 // KiB units (512 u16) from the tile's bases
+#pragma unroll
+        for (int s = 0; s < emsar::kTileSlices; s++) {
+            if (s < wave) { foff += T.k[s]; boff += T.m[s]; coo_base += T.coo_n[s]; }
+            if (s == wave) { k = T.k[s]; m = T.m[s]; coo_n = T.coo_n[s]; }
+        }
+        // everything above is wave-uniform; say so, or the loops below are compiled as divergent code
+        k = __builtin_amdgcn_readfirstlane(k); m = __builtin_amdgcn_readfirstlane(m);
+        coo_n = __builtin_amdgcn_readfirstlane(coo_n); coo_base = __builtin_amdgcn_readfirstlane(coo_base);
+        foff = __builtin_amdgcn_readfirstlane(foff); boff = __builtin_amdgcn_readfirstlane(boff);
+        e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 2 + (size_t)foff * 512) + lane;
+        b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 2 + (size_t)boff * 512) + lane;
         if (MODE != MODE_SCATTER) load8_clamped(A, e, k < 8 ? k : 8);
         if (m > 0) load8_clamped(B, b, m < 8 ? m : 8);
     }
