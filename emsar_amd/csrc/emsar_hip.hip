@@ -279,7 +279,8 @@ __global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restri
 // ------------------------------------------------------------------------------------------------
 constexpr int kTiledThreads = 256;                       // 4 wavefronts = 4 slices
 constexpr int kTiledWr = emsar::kTileSliceRows + 8;       // w_r of one slice + the zero padding row
-constexpr int kTiledLdsDoubles = 1024 + 1024 + emsar::kTileSlices * kTiledWr;
+constexpr int kTiledDictPad = emsar::kTileDict + 1;         // 960 slots incl. the zero slot
+constexpr int kTiledLdsDoubles = 2 * kTiledDictPad + emsar::kTileSlices * kTiledWr;   // 32,000 B: 5 workgroups per CU
 
 __device__ __forceinline__ double lds_at(const double *base, unsigned byte_off) {
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
@@ -335,7 +336,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 }
 
 template <bool WEIGHTED, int MODE, bool STAMP = false>
-__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__restrict__ tiles, const uint16_t *__restrict__ fwd,
+__global__ __launch_bounds__(kTiledThreads, 5) void k_pass_tiled(const Tile *__restrict__ tiles, const uint16_t *__restrict__ fwd,
                                                               const uint16_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
                                                               const int32_t *__restrict__ far_tid,
                                                               const int32_t *__restrict__ wgt,    // per row slot
@@ -343,8 +344,8 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
                                                               const double *__restrict__ theta, double *__restrict__ acc,
                                                               double *__restrict__ ll_out, unsigned long long *stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *th_w = lds;                 // [1024]
-    double *acc_w = lds + 1024;         // [1024]
+    double *th_w = lds;                     // [960]
+    double *acc_w = lds + kTiledDictPad;    // [960]
     __shared__ double red[kTiledThreads / 64];
     unsigned long long ts[6];
     if (STAMP) ts[0] = stamp_now();
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool has_slice = wave < (int)T.n_slices;
-    double *w_s = lds + 2048 + wave * kTiledWr;     // this wave's row weights [512] + zero row
+    double *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;     // this wave's row weights [512] + zero row
 
     // ---- issue every global load this wave needs first, in the order of use: dictionary values, 8 forward columns,
     //      8 backward segments.  One HBM round trip per tile; the rest of the pass touches LDS only.

@@ -34,7 +34,7 @@ namespace emsar {
 constexpr int kTileSlices = 4;         // wavefronts per workgroup
 constexpr int kTileSliceRows = 512;    // 64 lanes x 8 rows
 constexpr int kTileRows = kTileSlices * kTileSliceRows;
-constexpr int kTileDict = 1023;        // theta + acc windows in LDS: 2 x 8 KiB; +1 zero slot
+constexpr int kTileDict = 959;         // theta + acc windows in LDS: 2 x 7.5 KiB; +1 zero slot (5 workgroups per CU)
 constexpr int kMaxRowLen = 768;        // longer rows -> leftover CSR (a row must fit one dictionary)
 constexpr int kSegRows = 7;            // row offsets per backward segment (plus 1 header = 8 x u16 = one int4)
 constexpr int kDenseMin = 4;           // columns with fewer entries in a slice use the COO list
