@@ -109,6 +109,16 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "upload_and_layout": round(t_up, 2)},
             "mass_conserved": ok,
         }
+        # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the value is the
+        # committed rocprofv3 measurement of exactly this kernel + workload (profiles/traffic.json), else null
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            key = "%s/%s" % (args.config, out["config"]["layout"])
+            if args.scale == 1.0 and key in tr:
+                out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 PMC run of this kernel and workload)"
+        except (OSError, ValueError):
+            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(s, nnz)
     dev.close()
