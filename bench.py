@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads and transcripts (debug only)")
     ap.add_argument("--layout", default="auto", choices=["auto", "csr", "windowed", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solve", type=float, default=0.0, metavar="TOL",
+                    help="after the timed passes, also run the full solver (SQUAREM) to this tolerance and report passes/time")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,6 +89,12 @@ def main():
     mass = float((th * s["den"]).sum())
     ok = bool(np.isfinite(th).all() and abs(mass - s["n_reads"]) <= 1e-8 * s["n_reads"])
 
+    solve = None
+    if args.solve > 0:
+        t0 = time.perf_counter()
+        th_s, st = dev.solve(max_iter=200000, accel=1, tol=args.solve, check_every=4)
+        solve = {"tol": args.solve, "passes": st.iters, "converged": bool(st.converged), "seconds": time.perf_counter() - t0,
+                 "kernel_ms": st.kernel_ms, "loglik": st.loglik, "final_delta": st.final_delta}
     out = None
     if rank == 0:
         per_pass_s = kernel_ms / 1e3 / args.steps
@@ -109,6 +117,8 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "upload_and_layout": round(t_up, 2)},
             "mass_conserved": ok,
         }
+        if solve is not None:
+            out["solve_to_convergence"] = solve
         # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the value is the
         # committed rocprofv3 measurement of exactly this kernel + workload (profiles/traffic.json), else null
         try:
