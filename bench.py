@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solve", type=float, default=0.0, metavar="TOL",
                     help="after the timed passes, also run the full solver (SQUAREM) to this tolerance and report passes/time")
+    ap.add_argument("--solve-floor", type=float, default=1e-2,
+                    help="abs_floor of the stopping rule max|dtheta|/(theta+floor) in FPKM; boundary components decay like 1/k, "
+                         "so a floor at the print quantum (1e-6) is only reachable on small problems")
     args = ap.parse_args()
 
     import numpy as np
@@ -92,8 +95,8 @@ def main():
     solve = None
     if args.solve > 0:
         t0 = time.perf_counter()
-        th_s, st = dev.solve(max_iter=200000, accel=1, tol=args.solve, check_every=4)
-        solve = {"tol": args.solve, "passes": st.iters, "converged": bool(st.converged), "seconds": time.perf_counter() - t0,
+        th_s, st = dev.solve(max_iter=200000, accel=1, tol=args.solve, abs_floor=args.solve_floor, check_every=4)
+        solve = {"tol": args.solve, "abs_floor": args.solve_floor, "passes": st.iters, "converged": bool(st.converged), "seconds": time.perf_counter() - t0,
                  "kernel_ms": st.kernel_ms, "loglik": st.loglik, "final_delta": st.final_delta}
     out = None
     if rank == 0:
