@@ -51,8 +51,13 @@ def main():
     rank, world, local_rank = D.env_rank()
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # rehearsal knobs (one-GPU box): EMSAR_BENCH_BACKEND=gloo EMSAR_BENCH_DEVICE=0 lets several ranks share a card
+    backend = os.environ.get("EMSAR_BENCH_BACKEND", "nccl")
+    if "EMSAR_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["EMSAR_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    group = D.Group("nccl", torch.device("cuda", local_rank))   # RCCL; used for the barrier and max-over-ranks only
+    # RCCL (backend "nccl"); used for the barrier and the max-over-ranks of the timed region only
+    group = D.Group(backend, torch.device("cuda", local_rank) if backend == "nccl" else None)
 
     # ---- workload: one independent sample per rank ------------------------------------------------------
     cfg = dict(synth.CONFIGS[args.config])
