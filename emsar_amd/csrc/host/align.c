@@ -2,7 +2,7 @@
  *
  * Re-states, without the linked lists, what the reference does per read group:
  *   parse_bowtieline / parse_bowtieline_PE / read_bowtie_SE / read_bowtie_PE    emsar_functions.c:552-836
- *   convert_bam_alignment_2_alignment(_PE), read_BAM_SE/PE (SAM TEXT ONLY here)  emsar_functions.c:323-548
+ *   convert_bam_alignment_2_alignment(_PE), read_BAM_SE/PE (SAM text and BAM)   emsar_functions.c:323-548
  *   add_alignment_to_list, check_fraglen_discrepancy, parse_mmstr                alignment.c:29-108
  *   update_ReadCounts                                                            emsar_functions.c:838-943
  * Order of the filters for one read group (SURVEY.md 8a "input-side semantics"):
@@ -13,7 +13,7 @@
  *   5. discarded if the fragment length is outside [min,max] of the rsh header       emsar_functions.c:849
  *   6. tid multiset sorted ascending (duplicates kept) and looked up; a read whose set has no rsh node still
  *      counts in TotalReadCount and FraglengthCounts                                  emsar_functions.c:880-941
- * BAM is not read here (the reference vendors samtools 0.1.19 for it); SAM text covers the same records.
+ * BAM is read through zlib (BGZF = concatenated gzip members); the reference vendors samtools 0.1.19 for it.
  */
 #include "emsar_host.h"
 
@@ -21,9 +21,121 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <zlib.h>
+
 void *emsar_lr_open(const char *path);
 char *emsar_lr_next(void *h);
 void emsar_lr_close(void *h);
+
+/* One SAM/BAM alignment record reduced to what the reference reads from bam1_t (emsar_functions.c:391-469):
+ * qname, flag, reference name, 0-based position, l_qseq and the MD:Z string. */
+typedef struct { char qname[1024]; char rname[1024]; char md[4096]; int flag, pos, l_seq, unaligned; } samrec;
+
+/* ---- BAM: BGZF is a series of gzip members, which zlib's gzread() inflates transparently (SAM/BAM spec section 4).
+ * The reference reads BAM through its vendored samtools 0.1.19 (bam.c, bgzf.c); only the fields above are used. ---- */
+typedef struct { gzFile f; int n_ref; char **ref; unsigned char *buf; size_t cap; } bamreader;
+
+static int bam_rd(bamreader *b, void *dst, size_t n) { return gzread(b->f, dst, (unsigned)n) == (int)n ? 0 : -1; }
+static int32_t le32(const unsigned char *p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+
+static void bam_close(bamreader *b) {
+    if (!b) return;
+    if (b->f) gzclose(b->f);
+    if (b->ref) { for (int i = 0; i < b->n_ref; i++) free(b->ref[i]); free(b->ref); }
+    free(b->buf); free(b);
+}
+
+static bamreader *bam_open(const char *path) {
+    bamreader *b = (bamreader *)calloc(1, sizeof(*b));
+    if (!b) return NULL;
+    b->f = (path && path[0] && strcmp(path, "-") != 0) ? gzopen(path, "rb") : gzdopen(0, "rb");
+    unsigned char h[8];
+    if (!b->f || bam_rd(b, h, 8) || memcmp(h, "BAM\1", 4) != 0) { bam_close(b); return NULL; }
+    int32_t l_text = le32(h + 4);
+    if (l_text < 0) { bam_close(b); return NULL; }
+    for (int32_t i = 0; i < l_text; i++) { unsigned char c; if (bam_rd(b, &c, 1)) { bam_close(b); return NULL; } }
+    if (bam_rd(b, h, 4)) { bam_close(b); return NULL; }
+    b->n_ref = le32(h);
+    if (b->n_ref < 0 || b->n_ref > (1 << 28)) { bam_close(b); return NULL; }
+    b->ref = (char **)calloc((size_t)b->n_ref + 1, sizeof(char *));
+    if (!b->ref) { bam_close(b); return NULL; }
+    for (int i = 0; i < b->n_ref; i++) {
+        if (bam_rd(b, h, 4)) { bam_close(b); return NULL; }
+        int32_t ln = le32(h);
+        if (ln <= 0 || ln > 1 << 20) { bam_close(b); return NULL; }
+        b->ref[i] = (char *)malloc((size_t)ln);
+        if (!b->ref[i] || bam_rd(b, b->ref[i], (size_t)ln) || bam_rd(b, h, 4)) { bam_close(b); return NULL; }
+        b->ref[i][ln - 1] = 0;
+    }
+    return b;
+}
+
+/* returns 1 record read, 0 end of file, -1 malformed */
+static int bam_next(bamreader *b, samrec *r) {
+    unsigned char h[4];
+    int got = gzread(b->f, h, 4);
+    if (got == 0) return 0;
+    if (got != 4) return -1;
+    int32_t bs = le32(h);
+    if (bs < 32 || bs > (1 << 28)) return -1;
+    if ((size_t)bs > b->cap) { unsigned char *nb = (unsigned char *)realloc(b->buf, (size_t)bs); if (!nb) return -1; b->buf = nb; b->cap = (size_t)bs; }
+    if (bam_rd(b, b->buf, (size_t)bs)) return -1;
+    const unsigned char *p = b->buf;
+    int32_t refid = le32(p), pos = le32(p + 4), l_seq = le32(p + 16);
+    int l_name = p[8], n_cig = p[12] | (p[13] << 8), flag = p[14] | (p[15] << 8);
+    size_t off = 32;
+    if (off + (size_t)l_name > (size_t)bs || l_name < 1 || l_seq < 0) return -1;
+    snprintf(r->qname, sizeof r->qname, "%s", (const char *)(p + off));
+    off += (size_t)l_name + 4u * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    if (off > (size_t)bs) return -1;
+    r->flag = flag; r->pos = pos; r->l_seq = l_seq; r->md[0] = 0;
+    r->unaligned = refid < 0 || refid >= b->n_ref;
+    snprintf(r->rname, sizeof r->rname, "%s", r->unaligned ? "*" : b->ref[refid]);
+    while (off + 3 <= (size_t)bs) {                               /* auxiliary fields: find MD:Z */
+        const unsigned char *a = p + off;
+        char ty = (char)a[2];
+        off += 3;
+        size_t len;
+        switch (ty) {
+            case 'A': case 'c': case 'C': len = 1; break;
+            case 's': case 'S': len = 2; break;
+            case 'i': case 'I': case 'f': len = 4; break;
+            case 'Z': case 'H': {
+                size_t n = 0;
+                while (off + n < (size_t)bs && p[off + n]) n++;
+                if (off + n >= (size_t)bs) return -1;
+                if (a[0] == 'M' && a[1] == 'D' && ty == 'Z') snprintf(r->md, sizeof r->md, "%s", (const char *)(p + off));
+                len = n + 1; break;
+            }
+            case 'B': {
+                if (off + 5 > (size_t)bs) return -1;
+                char sub = (char)p[off]; int32_t cnt = le32(p + off + 1);
+                size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                if (cnt < 0) return -1;
+                len = 5 + es * (size_t)cnt; break;
+            }
+            default: return -1;
+        }
+        off += len;
+    }
+    return 1;
+}
+
+/* SAM text line -> samrec; returns 1 record, 0 header line, -1 malformed */
+static int sam_parse(char *line, samrec *r) {
+    if (line[0] == '@') return 0;
+    char *f[64];
+    int nf = 0;
+    f[nf++] = line;
+    for (char *p = line; *p; p++) if (*p == '\t') { *p = 0; if (nf < 64) f[nf++] = p + 1; else break; }
+    if (nf < 11) return -1;
+    snprintf(r->qname, sizeof r->qname, "%s", f[0]);
+    snprintf(r->rname, sizeof r->rname, "%s", f[2]);
+    r->flag = atoi(f[1]); r->pos = atoi(f[3]) - 1; r->l_seq = (int)strlen(f[9]); r->md[0] = 0;
+    r->unaligned = strcmp(f[2], "*") == 0;
+    for (int i = 11; i < nf; i++) if (strncmp(f[i], "MD:Z:", 5) == 0) snprintf(r->md, sizeof r->md, "%s", f[i] + 5);
+    return 1;
+}
 
 typedef struct { int32_t tid, mm, fraglen, pos; } aln;
 typedef struct { aln *a; int n, cap; int min_mm; } alist;
@@ -122,6 +234,7 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
     *out = NULL;
     emsar_counts *c = (emsar_counts *)calloc(1, sizeof(*c));
     void *lr = NULL;
+    bamreader *bam = NULL;
     alist l = {NULL, 0, 0, 10000};
     int32_t *tmp = NULL; int tmpcap = 0;
     char *prev = NULL; size_t prevcap = 0;
@@ -133,57 +246,56 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
     c->frag_counts = (int32_t *)calloc((size_t)c->n_frag, sizeof(int32_t));
     c->readlength = r->hdr_readlength;
     if (!c->R || !c->frag_counts) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
-    lr = emsar_lr_open(path);
-    if (!lr) FAIL(EMSAR_HOST_ERR_IO, "can't open alignment file %s", path);
+    if (o->format == 2) {
+        bam = bam_open(path);
+        if (!bam) FAIL(EMSAR_HOST_ERR_IO, "can't open BAM file %s", path);
+    } else {
+        lr = emsar_lr_open(path);
+        if (!lr) FAIL(EMSAR_HOST_ERR_IO, "can't open alignment file %s", path);
+    }
 
-    char *line;
+    char *line = NULL;
     int have_prev = 0;
-    while ((line = emsar_lr_next(lr))) {
+    samrec r1, r2;
+    for (;;) {
         aln x; char *rid = NULL; int keep = 0;
         char idbuf[1024];
-        if (o->format == 1) {                                        /* ---------- SAM text ---------- */
-            if (line[0] == '@') continue;
-            char *f[64];
-            int nf = split_tabs(line, f, 64);
-            if (nf < 11) FAIL(EMSAR_HOST_ERR_FORMAT, "SAM record with %d fields", nf);
-            if (strcmp(f[2], "*") == 0) continue;                    /* unaligned (core.tid == -1) */
-            int flag = atoi(f[1]);
-            const char *md = "";
-            for (int i = 11; i < nf; i++) if (strncmp(f[i], "MD:Z:", 5) == 0) md = f[i] + 5;
+        if (o->format != 0) {                                        /* ---------- SAM text / BAM ---------- */
+            int st;
+            if (bam) st = bam_next(bam, &r1);
+            else { line = emsar_lr_next(lr); st = line ? sam_parse(line, &r1) : -2; if (st == 0) continue; if (st == -2) st = 0; }
+            if (st == 0) break;
+            if (st < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "malformed %s record", bam ? "BAM" : "SAM");
+            if (r1.unaligned) continue;                               /* core.tid == -1 (359, 515) */
             if (!o->pe) {
-                int32_t tid = emsar_rsh_tid_of(r, f[2]);
-                if (tid < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "unknown transcript %s in the alignment file", f[2]);
-                char strand = (flag & 0x10) ? '-' : '+';
-                rid = f[0];
+                int32_t tid = emsar_rsh_tid_of(r, r1.rname);
+                if (tid < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "unknown transcript %s in the alignment file", r1.rname);
+                char strand = (r1.flag & 0x10) ? '-' : '+';
+                rid = r1.qname;
                 if (!(o->strand != 0 && o->strand != strand)) {
-                    x.tid = tid; x.mm = parse_sam_md(md); x.fraglen = (int32_t)strlen(f[9]); x.pos = atoi(f[3]) - 1; keep = 1;
+                    x.tid = tid; x.mm = parse_sam_md(r1.md); x.fraglen = r1.l_seq; x.pos = r1.pos; keep = 1;
                 }
             } else {                                                  /* mate on the next record (514-520) */
-                size_t L1 = strlen(line);  (void)L1;
-                /* copy what we need from record 1 before the reader reuses its buffer */
-                char name1[1024], ref1[1024]; int flag1 = flag, pos1 = atoi(f[3]) - 1, len1 = (int)strlen(f[9]), mm1 = parse_sam_md(md);
-                snprintf(name1, sizeof name1, "%s", f[0]); snprintf(ref1, sizeof ref1, "%s", f[2]);
-                char *l2 = emsar_lr_next(lr);
-                if (!l2) break;
-                char *g[64];
-                int ng = split_tabs(l2, g, 64);
-                if (ng < 11) FAIL(EMSAR_HOST_ERR_FORMAT, "SAM record with %d fields", ng);
-                int flag2 = atoi(g[1]), pos2 = atoi(g[3]) - 1, len2 = (int)strlen(g[9]);
-                const char *md2 = "";
-                for (int i = 11; i < ng; i++) if (strncmp(g[i], "MD:Z:", 5) == 0) md2 = g[i] + 5;
-                int32_t tid = emsar_rsh_tid_of(r, ref1);
-                if (tid < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "unknown transcript %s in the alignment file", ref1);
-                if (c->readlength == -1) c->readlength = len1;
-                if (c->readlength != len1 || c->readlength != len2) FAIL(EMSAR_HOST_ERR_FORMAT, "paired-end data with variable read length is not supported");
+                if (bam) st = bam_next(bam, &r2);
+                else { char *l2 = emsar_lr_next(lr); st = l2 ? sam_parse(l2, &r2) : 0; }
+                if (st == 0) break;
+                if (st < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "malformed %s record", bam ? "BAM" : "SAM");
+                int32_t tid = emsar_rsh_tid_of(r, r1.rname);
+                if (tid < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "unknown transcript %s in the alignment file", r1.rname);
+                if (c->readlength == -1) c->readlength = r1.l_seq;
+                if (c->readlength != r1.l_seq || c->readlength != r2.l_seq) FAIL(EMSAR_HOST_ERR_FORMAT, "paired-end data with variable read length is not supported");
                 int p1, p2; char s1, s2;
-                if ((flag1 & 0x40) && (flag2 & 0x80)) { p1 = pos1; p2 = pos2; s1 = (flag1 & 0x10) ? '-' : '+'; s2 = (flag2 & 0x10) ? '-' : '+'; }
-                else if ((flag2 & 0x40) && (flag1 & 0x80)) { p1 = pos2; p2 = pos1; s1 = (flag2 & 0x10) ? '-' : '+'; s2 = (flag1 & 0x10) ? '-' : '+'; }
-                else FAIL(EMSAR_HOST_ERR_FORMAT, "mates are not grouped in the SAM file");
-                snprintf(idbuf, sizeof idbuf, "%s", name1); rid = idbuf;
-                x.tid = tid; x.mm = mm1 + parse_sam_md(md2);
+                const char *md1, *md2;
+                if ((r1.flag & 0x40) && (r2.flag & 0x80)) { p1 = r1.pos; p2 = r2.pos; s1 = (r1.flag & 0x10) ? '-' : '+'; s2 = (r2.flag & 0x10) ? '-' : '+'; md1 = r1.md; md2 = r2.md; }
+                else if ((r2.flag & 0x40) && (r1.flag & 0x80)) { p1 = r2.pos; p2 = r1.pos; s1 = (r2.flag & 0x10) ? '-' : '+'; s2 = (r1.flag & 0x10) ? '-' : '+'; md1 = r2.md; md2 = r1.md; }
+                else FAIL(EMSAR_HOST_ERR_FORMAT, "mates are not grouped in the SAM/BAM file");
+                snprintf(idbuf, sizeof idbuf, "%s", r1.qname); rid = idbuf;
+                x.tid = tid; x.mm = parse_sam_md(md1) + parse_sam_md(md2);
                 if (p2 > p1) { x.fraglen = p2 - p1 + c->readlength; x.pos = p1; keep = !(o->strand == '-') && (s1 == '+' && s2 == '-'); }
                 else { x.fraglen = p1 - p2 + c->readlength; x.pos = p2; keep = !(o->strand == '+') && (s1 == '-' && s2 == '+'); }
             }
+        } else if (!(line = emsar_lr_next(lr))) {
+            break;
         } else if (!o->pe) {                                          /* ---------- default bowtie, single-end (552-587) ---------- */
             char *f[9];
             int nf = split_tabs(line, f, 9);
@@ -241,6 +353,7 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
     if (flush_group(r, o, &l, c, &tmp, &tmpcap) < 0) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
 done:
     emsar_lr_close(lr);
+    bam_close(bam);
     free(l.a); free(tmp); free(prev); free(line2);
     if (rc != EMSAR_HOST_OK) { emsar_counts_free(c); return rc; }
     *out = c;

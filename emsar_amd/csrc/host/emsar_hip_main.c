@@ -5,10 +5,10 @@
  *   emsar-hip [options] -M -I index.rsh outdir outprefix alignmentfilelist     (one alignment file per line)
  *
  * Same option letters as the reference for everything that reaches this path (emsar_main.c:100-214):
- *   -I rsh  -P  -s strand  -k max_repeat  -n rounds  -e tol  -i max_passes  -d delta  -g  -M  -S  -q  -v  -p threads(ignored)
+ *   -I rsh  -P  -s strand  -k max_repeat  -n rounds  -e tol  -i max_passes  -d delta  -g  -M  -S  -B  -q  -v  -p threads(ignored)
  * plus  --gpus N (devices used by -M, default all), --device D (single sample), --plain (no SQUAREM),
  *       --stats-json FILE.
- * Not taken over: -x fasta (index build, emsar-build's job), -B BAM (use -S with SAM text), -m positional bias
+ * Not taken over: -x fasta (index build, emsar-build's job), -m positional bias
  * (unfinished in the reference, emsar_main.c:371), -F/-f (the reference overwrites both from the rsh header,
  * emsar_functions.c:1419-1420, so they have no effect with -I).
  *
@@ -143,7 +143,7 @@ static void usage(const char *a0) {
             "  -I, --rsh <file>        rsh index (from emsar-build)            [required]\n"
             "  -M, --multisample       last argument lists one alignment file per line; samples are spread over GPUs\n"
             "  -P, --PE                paired-end          -s, --strand_type ns|ssf|ssr|ssfr|ssrf (default ns)\n"
-            "  -S, --SAM               SAM text input (default: default bowtie output)\n"
+            "  -S, --SAM / -B, --BAM   SAM text / BAM input (default: default bowtie output)\n"
             "  -k, --max_repeat <n>    reads with more alignments are discarded (default 100)\n"
             "  -n, --nround <n>        rounds reported in the mean/sd columns (default 4; the EM is deterministic)\n"
             "  -e, --epsilon <tol>     EM stops when max |dtheta|/(theta+1e-6) < tol (default 1e-10)\n"
@@ -161,12 +161,12 @@ int main(int argc, char **argv) {
         {"rsh", required_argument, 0, 'I'}, {"PE", no_argument, 0, 'P'}, {"strand_type", required_argument, 0, 's'},
         {"maxthread", required_argument, 0, 'p'}, {"max_repeat", required_argument, 0, 'k'}, {"nround", required_argument, 0, 'n'},
         {"epsilon", required_argument, 0, 'e'}, {"max_niter_mle", required_argument, 0, 'i'}, {"delta", required_argument, 0, 'd'},
-        {"print_segments", no_argument, 0, 'g'}, {"multisample", no_argument, 0, 'M'}, {"SAM", no_argument, 0, 'S'},
+        {"print_segments", no_argument, 0, 'g'}, {"multisample", no_argument, 0, 'M'}, {"SAM", no_argument, 0, 'S'}, {"BAM", no_argument, 0, 'B'},
         {"verbose", no_argument, 0, 'v'}, {"no_verbose", no_argument, 0, 'q'}, {"gpus", required_argument, 0, 1000},
         {"device", required_argument, 0, 1001}, {"plain", no_argument, 0, 1002}, {"stats-json", required_argument, 0, 1003},
         {"maxfraglen", required_argument, 0, 'F'}, {"minfraglen", required_argument, 0, 'f'}, {0, 0, 0, 0}};
     int c;
-    while ((c = getopt_long(argc, argv, "vqPs:p:F:f:n:e:d:gMSk:i:I:", lo, NULL)) != -1) {
+    while ((c = getopt_long(argc, argv, "vqPs:p:F:f:n:e:d:gMSBk:i:I:", lo, NULL)) != -1) {
         switch (c) {
             case 'I': cfg.rsh_path = optarg; break;
             case 'P': cfg.ao.pe = 1; break;
@@ -181,6 +181,7 @@ int main(int argc, char **argv) {
             case 'g': cfg.print_segments = 1; break;
             case 'M': multisample = 1; break;
             case 'S': cfg.ao.format = 1; break;
+            case 'B': cfg.ao.format = 2; break;
             case 'v': cfg.verbose = 2; break;
             case 'q': cfg.verbose = 0; break;
             case 1000: gpus = atoi(optarg); break;

@@ -3,7 +3,7 @@
  * reading its inputs and calling the solver, and what it prints afterwards:
  *
  *   rsh text reader           construct_rsh_from_rshfile      /root/reference/src/emsar_functions.c:1351-1510
- *   alignment readers         read_bowtie_SE/PE, read_BAM_* (SAM text only)   emsar_functions.c:323-836
+ *   alignment readers         read_bowtie_SE/PE, read_BAM_* (SAM text and BAM)  emsar_functions.c:323-836
  *   per-read collapse         add_alignment_to_list + update_ReadCounts       alignment.c:29-95, emsar_functions.c:838-943
  *   fragment-length weights   transfer_fraglendist_to_Wf, compute_adjEUMA     emsar_functions.c:2503-2523
  *   row order (cid)           scan_rshbucket                                  emsar_functions.c:2135-2192
@@ -54,7 +54,7 @@ typedef struct {
     int pe;              /* -P */
     char strand;         /* library_strand_type: 0, '+', '-'  (set_library_strand_type, emsar_functions.c:16-22) */
     int max_repeat;      /* -k, default 100 */
-    int format;          /* 0 default-bowtie text, 1 SAM text */
+    int format;          /* 0 default-bowtie text, 1 SAM text, 2 BAM */
 } emsar_aln_opts;
 
 typedef struct {

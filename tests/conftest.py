@@ -10,11 +10,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["toy5_se50", "toy5_sam", "toy5_pe", "toy5_pe_sam", "syn300_se", "syn300_k2", "syn2k_se"]
+CASES = ["toy5_se50", "toy5_sam", "toy5_bam", "toy5_pe", "toy5_pe_sam", "toy5_pe_bam", "syn300_se", "syn300_k2", "syn2k_se"]
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver on the GPU box)")
+
+
+def aln_path(case_dir):
+    """The alignment input of a fixture (bowtie/SAM text gzipped, or BAM) and its emsar format code."""
+    import glob
+    p = (glob.glob(os.path.join(case_dir, "reads.*.gz")) + glob.glob(os.path.join(case_dir, "reads.bam")))[0]
+    return p, (2 if p.endswith(".bam") else 1 if ".sam" in p else 0)
 
 
 class Fixture:

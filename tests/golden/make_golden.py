@@ -56,6 +56,53 @@ def sam_line(rid, flag, tname, pos0, length, md, mate=""):
         rid, flag, tname, pos0 + 1, length, mate or "*", "A" * length, "I" * length, md)
 
 
+def sam_to_bam(sam_path, bam_path):
+    """Minimal SAM text -> BAM (BGZF) writer, enough for the records this script emits (single-op CIGAR, Z/i tags).
+    Layout: SAM/BAM specification section 4; BGZF blocks carry the 'BC' extra field the reference's bgzf.c reads."""
+    import struct
+    import zlib
+    text, refs, recs = "", [], []
+    for line in open(sam_path):
+        if line.startswith("@"):
+            text += line
+            if line.startswith("@SQ"):
+                f = dict(x.split(":", 1) for x in line.rstrip("\n").split("\t")[1:])
+                refs.append((f["SN"], int(f["LN"])))
+        else:
+            recs.append(line.rstrip("\n").split("\t"))
+    rid = {n: i for i, (n, _) in enumerate(refs)}
+    out = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs)))
+    for n, ln in refs:
+        out += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln)
+    code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    for f in recs:
+        name, flag, rname, pos, mapq, cigar, rnext, pnext, tlen, seq, qual = f[:11]
+        flag, pos, mapq, pnext, tlen = int(flag), int(pos), int(mapq), int(pnext), int(tlen)
+        ref = -1 if rname == "*" else rid[rname]
+        nref = -1 if rnext == "*" else (ref if rnext == "=" else rid[rnext])
+        cig = b"" if cigar == "*" else struct.pack("<I", (int(cigar[:-1]) << 4) | "MIDNSHP=X".index(cigar[-1]))
+        l_seq = len(seq)
+        packed = bytearray((l_seq + 1) // 2)
+        for i, c in enumerate(seq):
+            packed[i // 2] |= code[c] << (4 if i % 2 == 0 else 0)
+        q = bytes(ord(c) - 33 for c in qual) if qual != "*" else b"\xff" * l_seq
+        aux = b""
+        for tag in f[11:]:
+            t, ty, v = tag.split(":", 2)
+            aux += t.encode() + (b"Z" + v.encode() + b"\0" if ty == "Z" else b"i" + struct.pack("<i", int(v)))
+        body = struct.pack("<iiBBHHHiiii", ref, pos - 1, len(name) + 1, mapq, 4680, 0 if cigar == "*" else 1, flag, l_seq,
+                           nref, pnext - 1, tlen) + name.encode() + b"\0" + cig + bytes(packed) + q + aux
+        out += struct.pack("<i", len(body)) + body
+    with open(bam_path, "wb") as fo:
+        for i in range(0, len(out), 60000):
+            chunk = bytes(out[i:i + 60000])
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            data = c.compress(chunk) + c.flush()
+            fo.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(data) + 25) + data +
+                     struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        fo.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))   # BGZF EOF block
+
+
 def run_reference(case_dir, rsh, aln, extra_opts, runs=RUNS):
     out = os.path.join(case_dir, "_out")
     for r in range(runs):
@@ -251,7 +298,7 @@ def toy5_transcripts():
             ("tD", ex[5]), ("tE", ex[3] + ex[4] + ex[3])]
 
 
-def case_toy5_sam(case_dir):
+def case_toy5_sam(case_dir, bam=False):
     """Same model as toy5_se50 but the reads come as SAM text (-S): exercises the MD:Z mismatch count,
     the 0x10 strand bit, unaligned records and 1-based POS."""
     rng = random.Random(17)
@@ -285,16 +332,22 @@ def case_toy5_sam(case_dir):
     aln = os.path.join(case_dir, "reads.sam")
     with open(aln, "w") as f:
         f.writelines(lines)
-    cmd = run_reference(case_dir, os.path.join(case_dir, "index.rsh"), aln, ["-S"])
-    gzip_inplace(aln)
-    return {"n_reads_emitted": n_reads, "total_read_count": n_reads, "opts": ["-S"], "cmd": " ".join(cmd)}
+    if bam:
+        sam_to_bam(aln, os.path.join(case_dir, "reads.bam"))
+        os.remove(aln)
+        aln = os.path.join(case_dir, "reads.bam")
+    opts = ["-B"] if bam else ["-S"]
+    cmd = run_reference(case_dir, os.path.join(case_dir, "index.rsh"), aln, opts)
+    if not bam:
+        gzip_inplace(aln)
+    return {"n_reads_emitted": n_reads, "total_read_count": n_reads, "opts": opts, "cmd": " ".join(cmd)}
 
 
 def revcomp(s_):
     return s_[::-1].translate(str.maketrans("ACGT", "TGCA"))
 
 
-def case_toy5_pe(case_dir, sam=False):
+def case_toy5_pe(case_dir, sam=False, bam=False):
     """Paired-end: real emsar-build --PE index (fragment lengths 150-160), pairs as default-bowtie text or SAM."""
     rng = random.Random(27 + sam)
     tx = toy5_transcripts()
@@ -341,9 +394,14 @@ def case_toy5_pe(case_dir, sam=False):
     aln = os.path.join(case_dir, "reads.sam" if sam else "reads.bowtie")
     with open(aln, "w") as f:
         f.writelines(lines)
-    opts = ["-P"] + (["-S"] if sam else [])
+    if bam:
+        sam_to_bam(aln, os.path.join(case_dir, "reads.bam"))
+        os.remove(aln)
+        aln = os.path.join(case_dir, "reads.bam")
+    opts = ["-P"] + (["-B"] if bam else ["-S"] if sam else [])
     cmd = run_reference(case_dir, os.path.join(case_dir, "index.rsh"), aln, opts)
-    gzip_inplace(aln)
+    if not bam:
+        gzip_inplace(aln)
     return {"n_reads_emitted": n_reads, "total_read_count": None, "opts": opts, "cmd": " ".join(cmd)}
 
 
@@ -352,6 +410,8 @@ CASES = {
     "toy5_sam": case_toy5_sam,
     "toy5_pe": case_toy5_pe,
     "toy5_pe_sam": lambda d: case_toy5_pe(d, sam=True),
+    "toy5_bam": lambda d: case_toy5_sam(d, bam=True),
+    "toy5_pe_bam": lambda d: case_toy5_pe(d, sam=True, bam=True),
     "syn300_se": lambda d: synth_rsh_case(d, seed=11, n_tx=300, minfrag=40, maxfrag=44, n_reads=6000, opts=[]),
     "syn300_k2": lambda d: synth_rsh_case(d, seed=12, n_tx=300, minfrag=36, maxfrag=36, n_reads=4000,
                                           opts=["-k", "2"]),

@@ -9,7 +9,7 @@ import pytest
 
 import oracle as O
 from emsar_amd import _build
-from tests.conftest import CASES, get_fixture
+from tests.conftest import CASES, aln_path, get_fixture
 
 pytestmark = pytest.mark.gpu
 CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "emsar_amd", "emsar-hip")
@@ -22,7 +22,7 @@ def _built():
 
 
 def _aln(fx):
-    return glob.glob(os.path.join(fx.dir, "reads.*.gz"))[0]
+    return aln_path(fx.dir)[0]
 
 
 def _check_fpkm_file(fx, path):

@@ -12,6 +12,7 @@ import pytest
 
 import oracle as O
 from emsar_amd import _build, hostlib as HL
+from tests.conftest import aln_path
 
 HALF_QUANTUM = 5.01e-7
 
@@ -25,8 +26,9 @@ def _host(golden):
     r = HL.HostRsh(os.path.join(golden.dir, "index.rsh"))
     opts = golden.meta["opts"]
     k = int(opts[opts.index("-k") + 1]) if "-k" in opts else 100
-    aln = glob.glob(os.path.join(golden.dir, "reads.*.gz"))[0]
-    c = r.count(aln, pe=int("-P" in opts), fmt=int("-S" in opts), max_repeat=k)
+    aln, fmt = aln_path(golden.dir)
+    assert fmt == (2 if "-B" in opts else 1 if "-S" in opts else 0)
+    c = r.count(aln, pe=int("-P" in opts), fmt=fmt, max_repeat=k)
     return r, c, r.model(c)
 
 
@@ -153,3 +155,7 @@ def test_reader_error_paths(tmp_path):
         r.count(str(unk))
     with pytest.raises(HL.HostError):
         r.count(str(unk), strand="bogus")
+    notbam = tmp_path / "x.bam"
+    notbam.write_bytes(b"this is not a BAM file")
+    with pytest.raises(HL.HostError):
+        r.count(str(notbam), fmt=2)
