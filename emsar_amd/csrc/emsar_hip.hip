@@ -810,7 +810,12 @@ int scatter_rows(emsar_hip_ctx *ctx, const double *val_host, double *d_out) {
         const auto &L = ctx->TL;
         std::vector<double> slot((size_t)std::max<int64_t>(ctx->n_slots, 1), 0.0), left((size_t)std::max<int64_t>(ctx->n_left, 1), 0.0);
         std::vector<double> base((size_t)ctx->n_tx, 0.0);
-        for (int64_t i = 0; i < ctx->n_slots; i++) if (L.slot_row[(size_t)i] >= 0) slot[(size_t)i] = val_host[L.slot_row[(size_t)i]];
+        for (int64_t i = 0; i < ctx->n_slots; i++) {
+            int64_t r = L.slot_row[(size_t)i];
+            if (r < 0) continue;
+            if (L.merged) { double v = 0; for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) v += val_host[L.mem_row[(size_t)q]]; slot[(size_t)i] = v; }
+            else slot[(size_t)i] = val_host[r];
+        }
         for (int64_t i = 0; i < ctx->n_left; i++) left[(size_t)i] = val_host[L.left_row[(size_t)i]];
         for (size_t i = 0; i < L.single_row.size(); i++) base[(size_t)L.single_tid[i]] += val_host[L.single_row[i]];
         if (!ctx->d_rowval) HIPCHK(hipMalloc(&ctx->d_rowval, slot.size() * sizeof(double)));
@@ -900,7 +905,10 @@ void emsar_hip_destroy(emsar_hip_ctx *ctx) {
 int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr,
                                const int32_t *col_idx, int layout) {
     if (!ctx) return EMSAR_HIP_ERR_ARG;
+    const bool merge_rows = (layout & EMSAR_LAYOUT_FLAG_MERGE_ROWS) != 0;
+    layout &= ~EMSAR_LAYOUT_FLAG_MERGE_ROWS;
     if (layout != EMSAR_LAYOUT_AUTO && layout != EMSAR_LAYOUT_CSR && layout != EMSAR_LAYOUT_WINDOWED && layout != EMSAR_LAYOUT_TILED) return EMSAR_HIP_ERR_ARG;
+    if (merge_rows && layout != EMSAR_LAYOUT_AUTO && layout != EMSAR_LAYOUT_TILED) return EMSAR_HIP_ERR_ARG;
     if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -910,13 +918,14 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
     if (layout == EMSAR_LAYOUT_AUTO) {
         layout = (n_rows < ((int64_t)1 << 32)) ? EMSAR_LAYOUT_TILED : EMSAR_LAYOUT_CSR;
         if (const char *e = getenv("EMSAR_HIP_LAYOUT")) { int v = atoi(e); if (v >= 1 && v <= 3 && (v == 1 || n_rows < ((int64_t)1 << 32))) layout = v; }
+        if (merge_rows && layout != EMSAR_LAYOUT_TILED) return EMSAR_HIP_ERR_ARG;
     }
     ctx->layout = layout;
     const size_t T = (size_t)n_tx;
     try {
         if (layout == EMSAR_LAYOUT_TILED) {
             auto &L = ctx->TL;
-            if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L) != 0) return EMSAR_HIP_ERR_ARG;
+            if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows) != 0) return EMSAR_HIP_ERR_ARG;
             ctx->n_tiles = (int64_t)L.tiles.size(); ctx->n_slots = L.n_slots(); ctx->n_left = (int64_t)L.left_row.size();
             auto up = [&](void **dp, const void *src, size_t bytes) -> hipError_t {
                 hipError_t e = hipMalloc(dp, std::max<size_t>(bytes, 16));
@@ -998,10 +1007,10 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const int64_t n_rows = ctx->n_rows;
     // a row counts w = R (or 1) when it is inside the likelihood (E != 0), else 0
-    ctx->weighted = (row_weight != nullptr) || (row_E != nullptr);
+    ctx->weighted = (row_weight != nullptr) || (row_E != nullptr) || (ctx->layout == EMSAR_LAYOUT_TILED && ctx->TL.merged);
     ctx->loglik_const = 0.0;
     hipFree(ctx->d_wgt); ctx->d_wgt = nullptr;
-    if (ctx->weighted) {
+    if (row_weight || row_E) {
         for (int64_t r = 0; r < n_rows; r++) {
             if (row_weight && row_weight[r] < 0) return EMSAR_HIP_ERR_ARG;
             if (row_E && !(row_E[r] >= 0.0)) return EMSAR_HIP_ERR_ARG;  // negative or NaN
@@ -1027,6 +1036,18 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
             for (int64_t i = 0; i < ctx->n_slots; i++) {
                 int64_t r = L.slot_row[(size_t)i];
                 if (r < 0) continue;
+                if (L.merged) {                                   // a slot stands for all rows with this tid multiset
+                    int64_t sum = 0;
+                    for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) {
+                        int64_t o = L.mem_row[(size_t)q];
+                        int32_t x = weight_of(o);
+                        sum += x;
+                        if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[o]);
+                    }
+                    if (sum > INT32_MAX) return EMSAR_HIP_ERR_ARG;
+                    w[(size_t)i] = (int32_t)sum;
+                    continue;
+                }
                 int32_t x = weight_of(r);
                 w[(size_t)i] = x;
                 if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[r]);
@@ -1231,7 +1252,8 @@ int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *o) {
     if (!ctx || !o) return EMSAR_HIP_ERR_ARG;
     if (!ctx->have_structure) return EMSAR_HIP_ERR_STATE;
     memset(o, 0, sizeof(*o));
-    o->n_rows = ctx->n_rows; o->nnz = ctx->nnz; o->n_tx = ctx->n_tx; o->layout = ctx->layout; o->device_id = ctx->device;
+    o->n_rows = ctx->n_rows; o->nnz = ctx->nnz; o->n_tx = ctx->n_tx; o->device_id = ctx->device;
+    o->layout = ctx->layout | ((ctx->layout == EMSAR_LAYOUT_TILED && ctx->TL.merged) ? EMSAR_LAYOUT_FLAG_MERGE_ROWS : 0);
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
         o->n_chunks = ctx->n_tiles; o->n_slices = ctx->tl_n_fslices; o->padded_entries = ctx->tl_fwd_slots;
         o->far_entries = ctx->TL.far_entries; o->window = emsar::kTileDict;
@@ -1297,14 +1319,15 @@ int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
 }
 
 int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
-                                     emsar_hip_info *info_out) {
+                                     int merge_rows, emsar_hip_info *info_out) {
     if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
     emsar::TiledLayout L;
-    if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L) != 0) return EMSAR_HIP_ERR_ARG;
+    if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows != 0) != 0) return EMSAR_HIP_ERR_ARG;
     int rc = emsar::check_tiled(L, row_ptr, col_idx);
     if (info_out) {
         memset(info_out, 0, sizeof(*info_out));
-        info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx; info_out->layout = EMSAR_LAYOUT_TILED;
+        info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx;
+        info_out->layout = EMSAR_LAYOUT_TILED | (L.merged ? EMSAR_LAYOUT_FLAG_MERGE_ROWS : 0);
         info_out->n_chunks = (int64_t)L.tiles.size();
         info_out->n_slices = L.n_fslices;
         info_out->padded_entries = (int64_t)L.fwd.size(); info_out->far_entries = L.far_entries; info_out->window = emsar::kTileDict;

@@ -64,7 +64,10 @@ struct TiledLayout {
     std::vector<int32_t> single_tid;
     // tiles
     std::vector<Tile> tiles;
-    std::vector<int64_t> slot_row;      // row slot -> original row (-1 = padding)
+    std::vector<int64_t> slot_row;      // row slot -> original row, or merged-row id when `merged` (-1 = padding)
+    bool merged = false;                // identical rows were merged: a slot stands for mem_row[mem_ptr[id] .. mem_ptr[id+1])
+    std::vector<uint64_t> mem_ptr;
+    std::vector<uint32_t> mem_row;
     std::vector<uint16_t> fwd, bwd;
     std::vector<uint32_t> coo;          // (col_off << 16) | row_off
     std::vector<int32_t> far_tid;
@@ -76,10 +79,76 @@ struct TiledLayout {
     int64_t n_slots() const { return (int64_t)slot_row.size(); }
 };
 
-inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx, TiledLayout &out) {
+// With merge_rows, rows with the same tid multiset (2..kMaxRowLen tids) are stored once and weighted by the sum of
+// their members' weights -- what the reference's update_ReadCounts does when it counts reads per segment
+// (emsar_functions.c:838-943).  Every quantity the library computes is a sum over rows of a function of the row's tid
+// set times a per-row weight, so the merge is exact up to summation order.
+inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in, const int32_t *col_idx_in, TiledLayout &out,
+                       bool merge_rows = false) {
     if (n_rows >= (int64_t)1 << 32) return -1;
     out = TiledLayout();
-    out.n_rows = n_rows; out.n_tx = n_tx; out.nnz = (int64_t)row_ptr[n_rows];
+    const uint64_t *row_ptr = row_ptr_in;
+    const int32_t *col_idx = col_idx_in;
+    // merged view of the matrix (only built when asked for): unique rows with sorted tids
+    std::vector<uint64_t> m_ptr;
+    std::vector<int32_t> m_col;
+    std::vector<uint32_t> orig_of_merged;   // first member, for rows that are not merged (singles, long rows)
+    if (merge_rows) {
+        const int64_t nnz_in = (int64_t)row_ptr_in[n_rows];
+        std::vector<int32_t> scol((size_t)nnz_in);
+        std::vector<uint64_t> hash((size_t)n_rows, 0);
+        for (int64_t r = 0; r < n_rows; r++) {
+            uint64_t b = row_ptr_in[r], e = row_ptr_in[r + 1];
+            std::copy(col_idx_in + b, col_idx_in + e, scol.begin() + (int64_t)b);
+            std::sort(scol.begin() + (int64_t)b, scol.begin() + (int64_t)e);
+            uint64_t h = 1469598103934665603ull ^ (e - b);
+            for (uint64_t k = b; k < e; k++) { h ^= (uint64_t)(uint32_t)scol[(size_t)k]; h *= 1099511628211ull; }
+            hash[(size_t)r] = h;
+        }
+        uint64_t cap = 16;
+        while (cap < (uint64_t)n_rows * 2 + 2) cap <<= 1;
+        std::vector<int64_t> table((size_t)cap, -1);       // -> merged id
+        std::vector<int64_t> merged_of((size_t)n_rows, -1);
+        std::vector<uint32_t> cnt;                          // members per merged row
+        m_ptr.push_back(0);
+        for (int64_t r = 0; r < n_rows; r++) {
+            uint64_t b = row_ptr_in[r], e = row_ptr_in[r + 1], len = e - b;
+            bool mergeable = len >= 2 && len <= (uint64_t)kMaxRowLen;
+            int64_t id = -1;
+            if (mergeable) {
+                uint64_t h = hash[(size_t)r] & (cap - 1);
+                while (table[(size_t)h] >= 0) {
+                    int64_t o = table[(size_t)h];
+                    uint64_t ob = m_ptr[(size_t)o], oe = m_ptr[(size_t)o + 1];
+                    if (oe - ob == len && std::memcmp(m_col.data() + ob, scol.data() + b, len * 4) == 0) { id = o; break; }
+                    h = (h + 1) & (cap - 1);
+                }
+                if (id < 0) table[(size_t)h] = (int64_t)cnt.size();
+            }
+            if (id < 0) {
+                id = (int64_t)cnt.size();
+                m_col.insert(m_col.end(), scol.begin() + (int64_t)b, scol.begin() + (int64_t)e);
+                m_ptr.push_back((uint64_t)m_col.size());
+                cnt.push_back(0);
+                orig_of_merged.push_back((uint32_t)r);
+            }
+            merged_of[(size_t)r] = id;
+            cnt[(size_t)id]++;
+        }
+        const int64_t n_m = (int64_t)cnt.size();
+        out.mem_ptr.assign((size_t)n_m + 1, 0);
+        for (int64_t i = 0; i < n_m; i++) out.mem_ptr[(size_t)i + 1] = out.mem_ptr[(size_t)i] + cnt[(size_t)i];
+        out.mem_row.resize((size_t)n_rows);
+        std::vector<uint64_t> fillp(out.mem_ptr.begin(), out.mem_ptr.end() - 1);
+        for (int64_t r = 0; r < n_rows; r++) out.mem_row[(size_t)fillp[(size_t)merged_of[(size_t)r]]++] = (uint32_t)r;
+        out.merged = true;
+        row_ptr = m_ptr.data();
+        col_idx = m_col.data();
+        const int64_t n_rows_orig = n_rows;
+        n_rows = n_m;
+        out.n_rows = n_rows_orig; out.n_tx = n_tx; out.nnz = nnz_in;
+    }
+    if (!merge_rows) { out.n_rows = n_rows; out.n_tx = n_tx; out.nnz = (int64_t)row_ptr[n_rows]; }
     out.left_ptr.push_back(0);
 
     // ---- classify rows; keys of the tiled ones ----
@@ -89,9 +158,10 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, co
         uint64_t b = row_ptr[r], e = row_ptr[r + 1];
         uint64_t len = e - b;
         if (len == 0) continue;
-        if (len == 1) { out.single_row.push_back((uint32_t)r); out.single_tid.push_back(col_idx[b]); continue; }
+        const uint32_t r_orig = merge_rows ? orig_of_merged[(size_t)r] : (uint32_t)r;   // singles / long rows are never merged
+        if (len == 1) { out.single_row.push_back(r_orig); out.single_tid.push_back(col_idx[b]); continue; }
         if (len > (uint64_t)kMaxRowLen) {
-            out.left_row.push_back((uint32_t)r);
+            out.left_row.push_back(r_orig);
             out.left_col.insert(out.left_col.end(), col_idx + b, col_idx + e);
             out.left_ptr.push_back((uint64_t)out.left_col.size());
             continue;
@@ -300,6 +370,18 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
                     pf.push_back(((uint32_t)d << 16) | (uint32_t)i);
                 }
                 if (r < 0) { if (!a.empty()) return -5; continue; }
+                if (L.merged) {                                   // every member row has this tid multiset
+                    if (L.mem_ptr[(size_t)r + 1] == L.mem_ptr[(size_t)r]) return -6;
+                    for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) {
+                        uint32_t o = L.mem_row[(size_t)q];
+                        if (seen[o]) return -6;
+                        seen[o] = 1;
+                        b.assign(col_idx + row_ptr[o], col_idx + row_ptr[o + 1]);
+                        std::sort(b.begin(), b.end());
+                        if (a != b) return -7;
+                    }
+                    continue;
+                }
                 if (seen[(size_t)r]) return -6;
                 seen[(size_t)r] = 1;
                 b.assign(col_idx + row_ptr[r], col_idx + row_ptr[r + 1]);

@@ -10,6 +10,7 @@ _LIB_PATH = os.path.join(_PKG, "libemsar_hip.so")
 _lib = None
 
 LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_WINDOWED, LAYOUT_TILED = 0, 1, 2, 3
+FLAG_MERGE_ROWS = 0x100
 
 # every symbol include/emsar_hip.h declares (tests check that the library exports exactly these)
 SYMBOLS = [
@@ -75,7 +76,7 @@ def load_library():
     L.emsar_hip_normalise.argtypes = [vp, f64p, f64p, C.c_int64, f64p, f64p, i32p]
     L.emsar_hip_get_info.argtypes = [vp, C.POINTER(Info)]
     L.emsar_hip_layout_selfcheck.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int32, C.c_int64, C.POINTER(Info)]
-    L.emsar_hip_layout_selfcheck_tiled.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.POINTER(Info)]
+    L.emsar_hip_layout_selfcheck_tiled.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int, C.POINTER(Info)]
     _lib = L
     return L
 
@@ -107,13 +108,13 @@ def layout_selfcheck(n_tx, row_ptr, col_idx, window=0, chunk_entries=0):
     return info.as_dict()
 
 
-def layout_selfcheck_tiled(n_tx, row_ptr, col_idx):
+def layout_selfcheck_tiled(n_tx, row_ptr, col_idx, merge_rows=False):
     """Host-only: build + decode the TILED layout (no GPU needed).  Returns its statistics."""
     L = load_library()
     row_ptr, col_idx = _arr(row_ptr, np.uint64), _arr(col_idx, np.int32)
     info = Info()
     rc = L.emsar_hip_layout_selfcheck_tiled(len(row_ptr) - 1, n_tx, _p(row_ptr, C.c_uint64), _p(col_idx, C.c_int32),
-                                            C.byref(info))
+                                            int(merge_rows), C.byref(info))
     if rc != 0:
         raise EmsarHipError(rc, "layout_selfcheck_tiled")
     d = info.as_dict()
@@ -152,8 +153,10 @@ class EmsarHip:
         if rc != 0:
             raise EmsarHipError(rc, what, self._L.emsar_hip_last_error(self._h).decode())
 
-    def upload_structure(self, n_tx, row_ptr, col_idx, layout=LAYOUT_AUTO):
+    def upload_structure(self, n_tx, row_ptr, col_idx, layout=LAYOUT_AUTO, merge_rows=False):
         row_ptr, col_idx = _arr(row_ptr, np.uint64), _arr(col_idx, np.int32)
+        if merge_rows:
+            layout |= FLAG_MERGE_ROWS
         self._chk(self._L.emsar_hip_upload_structure(self._h, len(row_ptr) - 1, n_tx, _p(row_ptr, C.c_uint64),
                                                      _p(col_idx, C.c_int32), layout), "upload_structure")
         self.n_tx = int(n_tx)

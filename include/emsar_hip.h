@@ -49,6 +49,12 @@ typedef enum {
                                  single-tid rows folded into a per-transcript count */
 } emsar_hip_layout;
 
+/* OR-ed into the layout argument of emsar_hip_upload_structure (TILED only): store rows with the same tid multiset
+ * once, weighted by the sum of their members' weights -- the read -> segment collapse the reference does while it
+ * counts reads (update_ReadCounts, emsar_functions.c:838-943).  Exact up to summation order; per-row inputs of
+ * upload_sample / ieuma keep referring to the caller's rows. */
+#define EMSAR_LAYOUT_FLAG_MERGE_ROWS 0x100
+
 /* Replaces the solver knobs -e/-r/-i/-l/-n of the reference (emsar_main.c:86-91): the pattern search's
  * step/F epsilons have no meaning for an EM; they map to tol / max_iter. */
 typedef struct {
@@ -120,7 +126,7 @@ int emsar_hip_normalise(emsar_hip_ctx *ctx, const double *mean_fpkm, const doubl
 typedef struct {
     int64_t n_rows, nnz;
     int32_t n_tx;
-    int32_t layout;            /* layout in use */
+    int32_t layout;            /* layout in use (flags included) */
     int64_t n_chunks;          /* WINDOWED: chunks / TILED: tiles (one workgroup each) */
     int64_t n_slices;          /* WINDOWED: 256-row slices / TILED: 512-row forward slices */
     int64_t padded_entries;    /* stored forward slots incl. padding */
@@ -138,7 +144,7 @@ int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row
                                int32_t window, int64_t chunk_entries, emsar_hip_info *info_out);
 /* The same for the TILED layout (forward index, transposed index, dictionaries, folded and leftover rows). */
 int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
-                                     emsar_hip_info *info_out);
+                                     int merge_rows, emsar_hip_info *info_out);
 
 #ifdef __cplusplus
 }

@@ -92,9 +92,10 @@ def test_layout_roundtrip_edge_cases(lib):
     assert info["n_slices"] == 1 and info["padded_entries"] == 256 * 700
 
 
-def test_tiled_layout_roundtrip(lib, golden):
+@pytest.mark.parametrize("merge", [False, True])
+def test_tiled_layout_roundtrip(lib, golden, merge):
     m = golden.model
-    info = emsar_amd.layout_selfcheck_tiled(m.n_tx, m.row_ptr, m.col_idx)
+    info = emsar_amd.layout_selfcheck_tiled(m.n_tx, m.row_ptr, m.col_idx, merge)
     assert info["folded_single_rows"] >= m.n_tx                    # every transcript has a single-tid row in an rsh
 
 
@@ -103,6 +104,8 @@ def test_tiled_layout_roundtrip_synthetic(lib):
         m = synth.make_matrix(n_tx=6000, n_reads=60000, law=law, xfam=xfam, seed=3)
         info = emsar_amd.layout_selfcheck_tiled(m["n_tx"], m["row_ptr"], m["col_idx"])
         assert info["n_chunks"] >= 1
+        merged = emsar_amd.layout_selfcheck_tiled(m["n_tx"], m["row_ptr"], m["col_idx"], True)
+        assert merged["n_slices"] <= info["n_slices"] and merged["layout"] == 3 | 0x100
     # rows longer than a tile can hold, duplicates inside rows, empty rows
     rng = np.random.default_rng(1)
     rows = [rng.integers(0, 9000, size=3000), np.array([], dtype=np.int64), rng.integers(0, 9000, size=1025),
@@ -111,6 +114,12 @@ def test_tiled_layout_roundtrip_synthetic(lib):
     rp[1:] = np.cumsum([len(r) for r in rows])
     info = emsar_amd.layout_selfcheck_tiled(9000, rp, np.concatenate(rows).astype(np.int32))
     assert info["folded_single_rows"] == 1
+    # merging: the same multiset in any order is one stored row; repeated tids are part of the multiset
+    rows = [np.array([3, 1, 2]), np.array([2, 3, 1]), np.array([1, 2, 3]), np.array([1, 2]), np.array([5]), np.array([5]),
+            np.array([1, 1, 2]), np.array([2, 1, 1]), np.array([1, 2, 2])]
+    rp = np.zeros(len(rows) + 1, dtype=np.uint64)
+    rp[1:] = np.cumsum([len(r) for r in rows])
+    emsar_amd.layout_selfcheck_tiled(8, rp, np.concatenate(rows).astype(np.int32), True)
 
 
 def test_layout_roundtrip_golden(lib, golden):

@@ -14,7 +14,10 @@ from emsar_amd import EmsarHip, EmsarHipError, synth
 from emsar_amd.hip import LAYOUT_CSR, LAYOUT_TILED, LAYOUT_WINDOWED
 
 pytestmark = pytest.mark.gpu
-LAYOUTS = [LAYOUT_CSR, LAYOUT_WINDOWED, LAYOUT_TILED]
+from emsar_amd.hip import FLAG_MERGE_ROWS
+
+LAYOUT_TILED_MERGED = LAYOUT_TILED | FLAG_MERGE_ROWS      # identical rows stored once (read -> segment collapse)
+LAYOUTS = [LAYOUT_CSR, LAYOUT_WINDOWED, LAYOUT_TILED, LAYOUT_TILED_MERGED]
 
 
 @pytest.fixture(scope="module")
@@ -164,7 +167,7 @@ def test_collapsed_and_read_level_agree(dev):
     # the reference solves the collapsed (segment) form; the read-level matrix must give the same EM
     s = synth.make_matrix(n_tx=800, n_reads=30000, law="human", xfam=0.02, seed=4)
     rp, ci, cnt = synth.collapse(s["row_ptr"], s["col_idx"])
-    for layout in (LAYOUT_WINDOWED, LAYOUT_TILED):
+    for layout in (LAYOUT_WINDOWED, LAYOUT_TILED, LAYOUT_TILED_MERGED):
         dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], layout)
         dev.upload_sample(None, None, s["den"])
         dev.run_passes(25)
@@ -174,6 +177,18 @@ def test_collapsed_and_read_level_agree(dev):
         dev.run_passes(25)
         b = dev.get_theta()
         assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
+
+
+def test_merge_rows_reduces_the_stored_matrix(dev):
+    s = synth.make_matrix(n_tx=2000, n_reads=200000, law="human", xfam=0.02, seed=8)
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
+    a = dev.info()
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED, merge_rows=True)
+    b = dev.info()
+    assert b["layout"] == LAYOUT_TILED_MERGED and a["layout"] == LAYOUT_TILED
+    assert b["n_slices"] * 3 < a["n_slices"]                         # reads of one compatibility class collapse
+    with pytest.raises(EmsarHipError):                                # the flag belongs to the TILED layout only
+        dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_CSR | FLAG_MERGE_ROWS)
 
 
 def test_full_size_properties_cfg2(dev):
