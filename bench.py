@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads and transcripts (debug only)")
     ap.add_argument("--layout", default="auto", choices=["auto", "csr", "windowed", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--merge-rows", action="store_true",
+                    help="store identical rows once (read -> segment collapse at upload); NOT the headline configuration")
     ap.add_argument("--solve", type=float, default=0.0, metavar="TOL",
                     help="after the timed passes, also run the full solver (SQUAREM) to this tolerance and report passes/time")
     ap.add_argument("--solve-floor", type=float, default=1e-2,
@@ -72,7 +74,7 @@ def main():
     layout = {"auto": LAYOUT_AUTO, "csr": LAYOUT_CSR, "windowed": LAYOUT_WINDOWED, "tiled": 3}[args.layout]
     dev = EmsarHip(local_rank)
     t0 = time.time()
-    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], layout)
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], layout, merge_rows=args.merge_rows)
     dev.upload_sample(None, None, s["den"])
     t_up = time.time() - t0
     info = dev.info()
@@ -114,11 +116,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d reads x %d transcripts, nnz %d (mean %.2f aln/read), read-level CSR, one sample per GPU"
                        % (args.config, s["n_reads"], s["n_tx"], nnz, nnz / s["n_reads"]),
-                       "layout": {1: "csr", 2: "windowed", 3: "tiled"}[info["layout"]], "parallelism": "1 sample per GPU x %d" % world},
+                       "layout": {1: "csr", 2: "windowed", 3: "tiled", 259: "tiled+merged-rows"}[info["layout"]], "parallelism": "1 sample per GPU x %d" % world},
             "read_alignments_per_s": world * nnz * args.steps / wall,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": {1: "k_pass_csr", 2: "k_pass_windowed", 3: "k_pass_tiled"}[info["layout"]] + "+k_update",
+                         "kernel": {1: "k_pass_csr", 2: "k_pass_windowed", 3: "k_pass_tiled", 259: "k_pass_tiled"}[info["layout"]] + "+k_update",
                          "algorithmic_bytes_per_pass": bytes_pass, "stored_bytes_per_pass": info["stored_bytes_per_pass"],
                          "device_ms_per_pass": per_pass_s * 1e3},
             "layout_stats": {k: info[k] for k in ("n_chunks", "n_slices", "padded_entries", "far_entries", "window")},

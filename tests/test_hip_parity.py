@@ -186,7 +186,7 @@ def test_merge_rows_reduces_the_stored_matrix(dev):
     dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED, merge_rows=True)
     b = dev.info()
     assert b["layout"] == LAYOUT_TILED_MERGED and a["layout"] == LAYOUT_TILED
-    assert b["n_slices"] * 3 < a["n_slices"]                         # reads of one compatibility class collapse
+    assert b["n_slices"] * 2 < a["n_slices"]                         # reads of one compatibility class collapse
     with pytest.raises(EmsarHipError):                                # the flag belongs to the TILED layout only
         dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_CSR | FLAG_MERGE_ROWS)
 
