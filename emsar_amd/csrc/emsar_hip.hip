@@ -709,6 +709,8 @@ namespace {
         }                                                                                              \
     } while (0)
 
+inline void dfree(void *p) { if (p) (void)hipFree(p); }
+
 inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
 
 // bytes one pass actually streams in the chosen layout: index arrays + row weights + the T-sized vectors
@@ -718,18 +720,18 @@ inline int64_t stored_bytes(const emsar_hip_ctx *ctx) {
 }
 
 void free_structure(emsar_hip_ctx *ctx) {
-    hipFree(ctx->d_row_ptr); hipFree(ctx->d_col); hipFree(ctx->d_chunks); hipFree(ctx->d_slice_off); hipFree(ctx->d_ent);
+    dfree(ctx->d_row_ptr); dfree(ctx->d_col); dfree(ctx->d_chunks); dfree(ctx->d_slice_off); dfree(ctx->d_ent);
     ctx->d_row_ptr = nullptr; ctx->d_col = nullptr; ctx->d_chunks = nullptr; ctx->d_slice_off = nullptr; ctx->d_ent = nullptr;
-    hipFree(ctx->d_wgt); hipFree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
-    hipFree(ctx->d_tiles); hipFree(ctx->d_fwd); hipFree(ctx->d_bwd); hipFree(ctx->d_coo); hipFree(ctx->d_far);
-    hipFree(ctx->d_left_ptr); hipFree(ctx->d_left_col); hipFree(ctx->d_left_wgt); hipFree(ctx->d_left_val); hipFree(ctx->d_u);
+    dfree(ctx->d_wgt); dfree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
+    dfree(ctx->d_tiles); dfree(ctx->d_fwd); dfree(ctx->d_bwd); dfree(ctx->d_coo); dfree(ctx->d_far);
+    dfree(ctx->d_left_ptr); dfree(ctx->d_left_col); dfree(ctx->d_left_wgt); dfree(ctx->d_left_val); dfree(ctx->d_u);
     ctx->d_tiles = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_coo = nullptr; ctx->d_far = nullptr;
     ctx->d_left_ptr = nullptr; ctx->d_left_col = nullptr; ctx->d_left_wgt = nullptr; ctx->d_left_val = nullptr; ctx->d_u = nullptr;
     ctx->TL = emsar::TiledLayout(); ctx->n_left = ctx->n_tiles = ctx->n_slots = 0;
-    hipFree(ctx->d_den); hipFree(ctx->d_acc); ctx->d_den = nullptr; ctx->d_acc = nullptr;
-    for (auto &p : ctx->d_th) { hipFree(p); p = nullptr; }
-    for (auto &p : ctx->d_tmp) { hipFree(p); p = nullptr; }
-    hipFree(ctx->d_itmp); ctx->d_itmp = nullptr;
+    dfree(ctx->d_den); dfree(ctx->d_acc); ctx->d_den = nullptr; ctx->d_acc = nullptr;
+    for (auto &p : ctx->d_th) { dfree(p); p = nullptr; }
+    for (auto &p : ctx->d_tmp) { dfree(p); p = nullptr; }
+    dfree(ctx->d_itmp); ctx->d_itmp = nullptr;
     ctx->L = emsar::WindowedLayout();
     ctx->have_structure = ctx->have_sample = false;
 }
@@ -891,14 +893,14 @@ int emsar_hip_create(emsar_hip_ctx **out, int device_id) {
 
 void emsar_hip_destroy(emsar_hip_ctx *ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_structure(ctx);
-    hipFree(ctx->d_scal);
-    if (ctx->h_scal) hipHostFree(ctx->h_scal);
-    if (ctx->ev0) hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) hipEventDestroy(ctx->ev1);
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    dfree(ctx->d_scal);
+    if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -1009,7 +1011,7 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
     // a row counts w = R (or 1) when it is inside the likelihood (E != 0), else 0
     ctx->weighted = (row_weight != nullptr) || (row_E != nullptr) || (ctx->layout == EMSAR_LAYOUT_TILED && ctx->TL.merged);
     ctx->loglik_const = 0.0;
-    hipFree(ctx->d_wgt); ctx->d_wgt = nullptr;
+    dfree(ctx->d_wgt); ctx->d_wgt = nullptr;
     if (row_weight || row_E) {
         for (int64_t r = 0; r < n_rows; r++) {
             if (row_weight && row_weight[r] < 0) return EMSAR_HIP_ERR_ARG;
@@ -1023,7 +1025,7 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
     };
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
         const auto &L = ctx->TL;
-        hipFree(ctx->d_left_wgt); ctx->d_left_wgt = nullptr;
+        dfree(ctx->d_left_wgt); ctx->d_left_wgt = nullptr;
         std::vector<double> u((size_t)ctx->n_tx, 0.0);
         for (size_t i = 0; i < L.single_row.size(); i++) {
             int32_t x = weight_of(L.single_row[i]);
@@ -1308,7 +1310,7 @@ int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
     std::vector<unsigned long long> h(nw * 8);
     HIPCHK(hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(d);
+    dfree(d);
     for (int i = 0; i < 7; i++) {
         double sum = 0;
         for (size_t w = 0; w < nw; w++) sum += (double)h[w * 8 + (size_t)i];
