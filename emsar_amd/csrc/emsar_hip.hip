@@ -531,7 +531,7 @@ __global__ void k_fill_start(int n, const double *__restrict__ den, double *__re
 // grid-stride, one atomicMax per workgroup (hundreds of same-address atomics cost ~12 ns each)
 __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
                                                 const double *__restrict__ den, const double *__restrict__ u /* folded single-tid rows, may be null */,
-                                                double *__restrict__ th_out, double abs_floor, Scal *scal) {
+                                                double *__restrict__ th_out, double abs_floor, double count_floor, Scal *scal) {
     __shared__ double red[4];
     double d = 0.0;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
@@ -540,7 +540,9 @@ __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict_
         double y = dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
         th_out[t] = y;
         acc[t] = 0.0;
-        double dd = fabs(y - x) / (fabs(y) + abs_floor);
+        double fl = abs_floor;
+        if (count_floor > 0.0 && dn > 0.0) fl = fmax(fl, count_floor / dn);    // floor expressed in inferred reads
+        double dd = fabs(y - x) / (fabs(y) + fl);
         if (!(dd == dd)) dd = __builtin_huge_val();  // NaN -> +inf so that the host sees it
         d = fmax(d, dd);
     }
@@ -696,6 +698,7 @@ struct emsar_hip_ctx {
     Scal *h_scal = nullptr;      // pinned
     int64_t bytes_formula = 0, bytes_stored = 0;
     int64_t tl_fwd_slots = 0, tl_n_fslices = 0;
+    double count_floor = 0.0;    // stopping-rule floor in reads for the current solve (emsar_em_params.count_floor)
 };
 
 namespace {
@@ -801,7 +804,7 @@ int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_l
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot]);
     if (rc) return rc;
     hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
-                       ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->d_scal);
+                       ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->d_scal);
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
 }
@@ -1148,11 +1151,13 @@ int emsar_hip_run_passes(emsar_hip_ctx *ctx, int32_t n_passes, float *elapsed_ms
 int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_out, emsar_em_stats *stats) {
     if (!ctx || !fpkm_out) return EMSAR_HIP_ERR_ARG;
     if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
-    emsar_em_params p = pp ? *pp : emsar_em_params{0, 1, 0, 0, 0, 0};
+    emsar_em_params p = pp ? *pp : emsar_em_params{0, 1, 0, 0, 0, 0, 0};
     if (p.max_iter <= 0) p.max_iter = 100000;
     if (p.tol <= 0) p.tol = 1e-10;
     if (p.abs_floor <= 0) p.abs_floor = 1e-6;
     if (p.check_every <= 0) p.check_every = 8;
+    if (!(p.count_floor >= 0.0)) return EMSAR_HIP_ERR_ARG;
+    ctx->count_floor = p.count_floor;
     HIPCHK(hipSetDevice(ctx->device));
     auto t0 = std::chrono::steady_clock::now();
     int rc = emsar_hip_reset_theta(ctx);
@@ -1200,6 +1205,7 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(fpkm_out, th[0], (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->count_floor = 0.0;
     for (int32_t t = 0; t < n; t++)
         if (!std::isfinite(fpkm_out[t])) { ctx->err = "non-finite theta"; return EMSAR_HIP_ERR_NUMERIC; }
     if (stats) {

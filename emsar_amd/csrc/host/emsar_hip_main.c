@@ -37,7 +37,7 @@ typedef struct {
     char **aln; int n_aln;
     emsar_aln_opts ao;
     int n_round, delta, print_segments, verbose, accel;
-    double tol; int max_iter;
+    double tol, count_floor; int max_iter;
     const char *stats_json;
 } config;
 
@@ -82,7 +82,7 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i) {
     if (!theta || !mean || !sd || !ieuma || !tpm || !ir || !iri || !rounds) { rc = EMSAR_HOST_ERR_OOM; goto done; }
 
     /* ---- the replaced call: run_MLE_threads() + construct_FPKMfinal, emsar_main.c:444-450 ---- */
-    emsar_em_params p = {cfg->max_iter, cfg->accel, cfg->tol, 0.0, 0, 0};
+    emsar_em_params p = {cfg->max_iter, cfg->accel, cfg->tol, 0.0, 0, 0, cfg->count_floor};
     if ((rc = emsar_hip_upload_sample(ctx, cnt->R, m->E_solver, NULL)) ||
         (rc = emsar_hip_solve(ctx, &p, theta, &w->stats[i]))) {
         fprintf(stderr, "alnfile[%d]: %s (%s)\n", i, emsar_hip_strerror(rc), emsar_hip_last_error(ctx));
@@ -150,6 +150,7 @@ static void usage(const char *a0) {
             "  -i, --max_niter_mle <n> cap on EM passes (default 200000)\n"
             "  -d, --delta <d>         10^d scaling of the effective lengths (default 0)\n"
             "  -g, --print_segments    also write .segments\n"
+            "      --count-floor <reads> stopping-rule floor in inferred reads (default 0 = off; e.g. 1e-3 for large samples)\n"
             "      --gpus <n> / --device <d> / --plain / --stats-json <file> / -q / -v\n", a0);
 }
 
@@ -164,6 +165,7 @@ int main(int argc, char **argv) {
         {"print_segments", no_argument, 0, 'g'}, {"multisample", no_argument, 0, 'M'}, {"SAM", no_argument, 0, 'S'}, {"BAM", no_argument, 0, 'B'},
         {"verbose", no_argument, 0, 'v'}, {"no_verbose", no_argument, 0, 'q'}, {"gpus", required_argument, 0, 1000},
         {"device", required_argument, 0, 1001}, {"plain", no_argument, 0, 1002}, {"stats-json", required_argument, 0, 1003},
+        {"count-floor", required_argument, 0, 1004},
         {"maxfraglen", required_argument, 0, 'F'}, {"minfraglen", required_argument, 0, 'f'}, {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "vqPs:p:F:f:n:e:d:gMSBk:i:I:", lo, NULL)) != -1) {
@@ -188,6 +190,7 @@ int main(int argc, char **argv) {
             case 1001: device = atoi(optarg); break;
             case 1002: cfg.accel = 0; break;
             case 1003: cfg.stats_json = optarg; break;
+            case 1004: cfg.count_floor = atof(optarg); if (cfg.count_floor < 0) { fprintf(stderr, "--count-floor must be >= 0.\n"); return 1; } break;
             default: usage(argv[0]); return 1;
         }
     }

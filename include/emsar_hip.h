@@ -64,6 +64,9 @@ typedef struct {
     double  abs_floor;    /* <=0 -> 1e-6, the %lf print quantum of the reference's .fpkm */
     int32_t check_every;  /* host looks at the device convergence word every this many cycles; <=0 -> 8 */
     int32_t reserved;
+    double  count_floor;  /* optional second floor, in READS: the floor of transcript t becomes max(abs_floor, count_floor/den_t).
+                             Transcripts whose optimum is the boundary theta = 0 with zero gradient decay like 1/k; a floor of
+                             e.g. 1e-3 inferred reads stops the solve once only such components still move.  0 = off. */
 } emsar_em_params;
 
 typedef struct {

@@ -179,6 +179,24 @@ def test_collapsed_and_read_level_agree(dev):
         assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
 
 
+def test_count_floor_stops_early_without_moving_expressed_transcripts(dev):
+    """Stopping-rule floor in reads: boundary components (optimum theta = 0, zero gradient) decay like 1/k and keep
+    the plain rule busy; with a floor of 1e-3 inferred reads the solve ends much earlier and every transcript that
+    holds reads is where the tight solve puts it."""
+    s = synth.make_matrix(n_tx=3000, n_reads=300000, law="human", xfam=0.02, seed=12)
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
+    dev.upload_sample(None, None, s["den"])
+    tight, st_t = dev.solve(max_iter=60000, accel=1, tol=1e-8, abs_floor=1e-6)
+    loose, st_l = dev.solve(max_iter=60000, accel=1, tol=1e-8, abs_floor=1e-6, count_floor=1e-3)
+    assert st_l.converged == 1 and st_l.iters < st_t.iters
+    reads = tight * s["den"]
+    big = reads > 1.0
+    assert np.all(np.abs(loose - tight)[big] <= 1e-4 * tight[big])
+    assert np.abs((loose - tight) * s["den"]).max() < 0.5             # nobody moved by half a read
+    with pytest.raises(EmsarHipError):
+        dev.solve(count_floor=-1.0)
+
+
 def test_merge_rows_reduces_the_stored_matrix(dev):
     s = synth.make_matrix(n_tx=2000, n_reads=200000, law="human", xfam=0.02, seed=8)
     dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
