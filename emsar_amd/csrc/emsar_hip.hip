@@ -268,23 +268,28 @@ __global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_pass_tiled: one EM pass over the TILED layout (layout_tiled.hpp).  One workgroup (8 waves) per tile.
-//   phase 0  dictionary: th_w[d] = theta[tid(d)], acc_w[d] = 0, zero slots
-//   phase E  wave s owns forward slice s (512 rows, lane = 8 rows): S_r = sum th_w[off]  (LDS reads only, 16-bit
-//            byte offsets, padding reads the zero slot: no branches), w_r = R_r / S_r -> LDS
-//   phase M  backward segments: a lane walks its few segments (15 row offsets + column header each), gathers
-//            w_r from LDS into a register sum and adds it to acc_w when the column changes; tiny columns via COO
-//   phase F  non-zero dictionary slots are flushed with one global FP64 atomic each
-// HBM traffic: 2 B per forward slot + 2 B per backward slot (16/15 + padding) -- no row_ptr, no 32-bit tids.
+// k_pass_tiled: one EM pass over the TILED layout (layout_tiled.hpp).  One workgroup = 4 waves = the 4 slices of a tile.
+//   phase 0  every global load the wave needs first is issued at once (dictionary theta values, 8 forward columns,
+//            8 backward segments); dictionary: th_w[d] = theta[tid(d)], acc_w[d] = 0, zero slots; barrier
+//   phase E  the wave owns one slice (768 rows, lane = 12 rows): S_r = sum th_w[id]  (LDS reads only, 10-bit ids,
+//            padding reads the zero slot: no branches), w_r = R_r / S_r -> the wave's own 6 KiB of LDS
+//   phase M  the SAME wave walks the transposed index of its rows: a lane's segments (column id + 11 row ids) are
+//            consecutive in column order; it gathers w_r from LDS into a register sum and adds it to acc_w when the
+//            column changes; tiny columns via a COO list.  No barrier between E and M.
+//   phase F  barrier; non-zero dictionary slots are flushed with one global FP64 atomic each
+// HBM traffic: 10 bits per forward slot + 128 bits per 11 backward entries -- no row_ptr, no 32-bit tids.
 // ------------------------------------------------------------------------------------------------
 constexpr int kTiledThreads = 256;                       // 4 wavefronts = 4 slices
-constexpr int kTiledWr = emsar::kTileSliceRows + 8;       // w_r of one slice + the zero padding row
-constexpr int kTiledDictPad = emsar::kTileDict + 1;         // 960 slots incl. the zero slot
-constexpr int kTiledLdsDoubles = 2 * kTiledDictPad + emsar::kTileSlices * kTiledWr;   // 32,000 B: 5 workgroups per CU
+constexpr int kRPL = emsar::kRowsPerLane;                 // 12 rows per lane = twelve 10-bit ids per int4
+constexpr int kTiledWr = emsar::kTileSliceRows + 8;       // w_r of one slice (768) + the zero padding row
+constexpr int kTiledDictPad = emsar::kTileDict + 1;       // 960 slots incl. the zero slot
+constexpr int kTiledLdsDoubles = 2 * kTiledDictPad + emsar::kTileSlices * kTiledWr;   // 40,192 B: 4 workgroups per CU
 
 __device__ __forceinline__ double lds_at(const double *base, unsigned byte_off) {
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
 }
+// field f (0,1,2) of a packed dword -> LDS byte offset of the double it names
+__device__ __forceinline__ unsigned id_off(unsigned dword, int f) { return ((dword >> (10 * f)) & 0x3FFu) << 3; }
 
 // 8 independent 16-byte loads; positions beyond n repeat position n-1 (an L1 hit) so that there is no control flow
 // between the loads and all of them are in flight together
@@ -293,36 +298,38 @@ __device__ __forceinline__ void load8_clamped(int4 (&q)[8], const int4 *e, int n
     for (int j = 0; j < 8; j++) q[j] = e[(size_t)(j < n ? j : n - 1) * 64];
 }
 
-// E-step sums of up to 8 forward columns held in registers (n is wave-uniform)
-__device__ __forceinline__ void fwd_sum_regs(const int4 (&q)[8], int n, const double *th_w, double (&S)[8]) {
+// E-step sums of up to 8 forward columns held in registers (n is wave-uniform); one int4 = this lane's 12 rows
+__device__ __forceinline__ void fwd_sum_regs(const int4 (&q)[8], int n, const double *th_w, double (&S)[kRPL]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         if (j < n) {
             const int4 t = q[j];
-            S[0] += lds_at(th_w, (unsigned)t.x & 0xFFFFu); S[1] += lds_at(th_w, (unsigned)t.x >> 16);
-            S[2] += lds_at(th_w, (unsigned)t.y & 0xFFFFu); S[3] += lds_at(th_w, (unsigned)t.y >> 16);
-            S[4] += lds_at(th_w, (unsigned)t.z & 0xFFFFu); S[5] += lds_at(th_w, (unsigned)t.z >> 16);
-            S[6] += lds_at(th_w, (unsigned)t.w & 0xFFFFu); S[7] += lds_at(th_w, (unsigned)t.w >> 16);
+            const unsigned d[4] = {(unsigned)t.x, (unsigned)t.y, (unsigned)t.z, (unsigned)t.w};
+#pragma unroll
+            for (int i = 0; i < kRPL; i++) S[i] += lds_at(th_w, id_off(d[i / 3], i % 3));
         }
     }
 }
 
-// M-step of up to 8 backward segments of one lane ({column, 7 row offsets} each).  A lane's segments are consecutive
+// M-step of up to 8 backward segments of one lane ({column, 11 row ids} each).  A lane's segments are consecutive
 // in column order: the running sum stays in a register and goes to the LDS accumulator when the column changes.
 __device__ __forceinline__ void bwd_sum_regs(const int4 (&q)[8], int n, const double *w_s, double *acc_w, unsigned &cur, double &part) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         if (j < n) {
             const int4 t = q[j];
-            const unsigned col = (unsigned)t.x & 0xFFFFu;
+            const unsigned d[4] = {(unsigned)t.x, (unsigned)t.y, (unsigned)t.z, (unsigned)t.w};
+            const unsigned col = id_off(d[0], 0);
             if (col != cur) {
                 if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
                 cur = col; part = 0.0;
             }
-            double s0 = lds_at(w_s, (unsigned)t.x >> 16) + lds_at(w_s, (unsigned)t.y & 0xFFFFu);
-            double s1 = lds_at(w_s, (unsigned)t.y >> 16) + lds_at(w_s, (unsigned)t.z & 0xFFFFu);
-            double s2 = lds_at(w_s, (unsigned)t.z >> 16) + lds_at(w_s, (unsigned)t.w & 0xFFFFu);
-            part += (s0 + s1) + (s2 + lds_at(w_s, (unsigned)t.w >> 16));
+            double s0 = lds_at(w_s, id_off(d[0], 1)) + lds_at(w_s, id_off(d[0], 2));
+            double s1 = lds_at(w_s, id_off(d[1], 0)) + lds_at(w_s, id_off(d[1], 1));
+            double s2 = lds_at(w_s, id_off(d[1], 2)) + lds_at(w_s, id_off(d[2], 0));
+            double s3 = lds_at(w_s, id_off(d[2], 1)) + lds_at(w_s, id_off(d[2], 2));
+            s0 += lds_at(w_s, id_off(d[3], 0)); s1 += lds_at(w_s, id_off(d[3], 1)); s2 += lds_at(w_s, id_off(d[3], 2));
+            part += (s0 + s1) + (s2 + s3);
         }
     }
 }
@@ -336,8 +343,8 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 }
 
 template <bool WEIGHTED, int MODE, bool STAMP = false>
-__global__ __launch_bounds__(kTiledThreads, 5) void k_pass_tiled(const Tile *__restrict__ tiles, const uint16_t *__restrict__ fwd,
-                                                              const uint16_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
+__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__restrict__ tiles, const uint32_t *__restrict__ fwd,
+                                                              const uint32_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
                                                               const int32_t *__restrict__ far_tid,
                                                               const int32_t *__restrict__ wgt,    // per row slot
                                                               const double *__restrict__ rowval,  // per row slot (MODE_SCATTER)
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(kTiledThreads, 5) void k_pass_tiled(const Tile *__r
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool has_slice = wave < (int)T.n_slices;
-    double *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;     // this wave's row weights [512] + zero row
+    double *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;     // this wave's row weights [768] + zero row
 
     // ---- issue every global load this wave needs first, in the order of use: dictionary values, 8 forward columns,
     //      8 backward segments.  One HBM round trip per tile; the rest of the pass touches LDS only.
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(kTiledThreads, 5) void k_pass_tiled(const Tile *__r
     int k = 0, m = 0;
     unsigned coo_base = T.coo_off, coo_n = 0;
     if (has_slice) {
-        unsigned foff = 0, boff = 0;                 // KiB units (512 u16) from the tile's bases
+        unsigned foff = 0, boff = 0;                 // KiB units (256 dwords) from the tile's bases
 #pragma unroll
         for (int s = 0; s < emsar::kTileSlices; s++) {
             if (s < wave) { foff += T.k[s]; boff += T.m[s]; coo_base += T.coo_n[s]; }
@@ -385,8 +392,8 @@ __global__ __launch_bounds__(kTiledThreads, 5) void k_pass_tiled(const Tile *__r
         k = __builtin_amdgcn_readfirstlane(k); m = __builtin_amdgcn_readfirstlane(m);
         coo_n = __builtin_amdgcn_readfirstlane(coo_n); coo_base = __builtin_amdgcn_readfirstlane(coo_base);
         foff = __builtin_amdgcn_readfirstlane(foff); boff = __builtin_amdgcn_readfirstlane(boff);
-        e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 2 + (size_t)foff * 512) + lane;
-        b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 2 + (size_t)boff * 512) + lane;
+        e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 4 + (size_t)foff * 256) + lane;
+        b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 4 + (size_t)boff * 256) + lane;
         if (MODE != MODE_SCATTER) load8_clamped(A, e, k < 8 ? k : 8);
         if (m > 0) load8_clamped(B, b, m < 8 ? m : 8);
     }
@@ -403,43 +410,47 @@ __global__ __launch_bounds__(kTiledThreads, 5) void k_pass_tiled(const Tile *__r
 
     double ll = 0.0;
     if (has_slice) {
-        // ---- E: row sums of this wave's 512 rows ----
-        const size_t slot0 = (size_t)T.row_base + (size_t)wave * emsar::kTileSliceRows + 8 * lane;
-        double w[8];
+        // ---- E: row sums of this wave's 768 rows ----
+        const size_t slot0 = (size_t)T.row_base + (size_t)wave * emsar::kTileSliceRows + kRPL * lane;
+        double w[kRPL];
         if (MODE == MODE_SCATTER) {
             const double2 *rv = reinterpret_cast<const double2 *>(rowval + slot0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) { double2 v = rv[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
+            for (int i = 0; i < kRPL / 2; i++) { double2 v = rv[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
         } else {
-            double S[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            double S[kRPL];
+#pragma unroll
+            for (int i = 0; i < kRPL; i++) S[i] = 0.0;
             for (int j0 = 0; j0 < k; j0 += 8) {
                 const int n0 = k - j0 < 8 ? k - j0 : 8;
                 if (j0) load8_clamped(A, e + (size_t)j0 * 64, n0);
                 fwd_sum_regs(A, n0, th_w, S);
             }
-            double r[8] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+            double r[kRPL];
+#pragma unroll
+            for (int i = 0; i < kRPL; i++) r[i] = 1.0;
             if (WEIGHTED) {
                 const int4 *rw = reinterpret_cast<const int4 *>(wgt + slot0);
-                int4 x = rw[0], y = rw[1];
-                r[0] = x.x; r[1] = x.y; r[2] = x.z; r[3] = x.w; r[4] = y.x; r[5] = y.y; r[6] = y.z; r[7] = y.w;
+#pragma unroll
+                for (int i = 0; i < kRPL / 4; i++) { int4 x = rw[i]; r[4 * i] = x.x; r[4 * i + 1] = x.y; r[4 * i + 2] = x.z; r[4 * i + 3] = x.w; }
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < kRPL; i++) {
                 bool live = (S[i] > 0.0) && (r[i] > 0.0);
                 w[i] = live ? r[i] / S[i] : 0.0;
                 if (MODE == MODE_EM_LL && live) ll += r[i] * log(S[i]);
             }
         }
-        double2 *dst = reinterpret_cast<double2 *>(w_s + 8 * lane);
+        double2 *dst = reinterpret_cast<double2 *>(w_s + kRPL * lane);
 #pragma unroll
-        for (int i = 0; i < 4; i++) dst[i] = make_double2(w[2 * i], w[2 * i + 1]);
+        for (int i = 0; i < kRPL / 2; i++) dst[i] = make_double2(w[2 * i], w[2 * i + 1]);
         // the M-step below reads rows written by OTHER lanes of this same wave: DS operations of one wave execute in
         // order, so only the compiler has to be kept from moving the reads up
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (STAMP) ts[3] = stamp_now();
-        // ---- M: column sums over the same 512 rows, through the slice's transposed index ----
+        // ---- M: column sums over the same 768 rows, through the slice's transposed index ----
         unsigned cur = 0xFFFFFFFFu;
         double part = 0.0;
         for (int j0 = 0; j0 < m; j0 += 8) {
@@ -450,8 +461,8 @@ __global__ __launch_bounds__(kTiledThreads, 5) void k_pass_tiled(const Tile *__r
         if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
         for (unsigned q = lane; q < coo_n; q += 64) {
             const unsigned p = coo[coo_base + q];
-            const double v = lds_at(w_s, p & 0xFFFFu);
-            if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + (p >> 16)), v);
+            const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
+            if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + ((p >> 16) << 3)), v);
         }
     } else if (STAMP) ts[3] = stamp_now();
     if (STAMP) ts[4] = stamp_now();
@@ -678,7 +689,7 @@ struct emsar_hip_ctx {
     // TILED layout
     emsar::TiledLayout TL;       // host copy keeps slot_row / single_* / left_row (index arrays freed after upload)
     Tile *d_tiles = nullptr;
-    uint16_t *d_fwd = nullptr, *d_bwd = nullptr;
+    uint32_t *d_fwd = nullptr, *d_bwd = nullptr;
     uint32_t *d_coo = nullptr;
     int32_t *d_far = nullptr;
     uint64_t *d_left_ptr = nullptr; int32_t *d_left_col = nullptr; int32_t *d_left_wgt = nullptr; double *d_left_val = nullptr;
@@ -938,18 +949,18 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
                 return e;
             };
             HIPCHK(up((void **)&ctx->d_tiles, L.tiles.data(), L.tiles.size() * sizeof(Tile)));
-            HIPCHK(up((void **)&ctx->d_fwd, L.fwd.data(), L.fwd.size() * 2));
-            HIPCHK(up((void **)&ctx->d_bwd, L.bwd.data(), L.bwd.size() * 2));
+            HIPCHK(up((void **)&ctx->d_fwd, L.fwd.data(), L.fwd.size() * 4));
+            HIPCHK(up((void **)&ctx->d_bwd, L.bwd.data(), L.bwd.size() * 4));
             HIPCHK(up((void **)&ctx->d_coo, L.coo.data(), L.coo.size() * 4));
             HIPCHK(up((void **)&ctx->d_far, L.far_tid.data(), L.far_tid.size() * 4));
             HIPCHK(up((void **)&ctx->d_left_ptr, L.left_ptr.data(), L.left_ptr.size() * 8));
             HIPCHK(up((void **)&ctx->d_left_col, L.left_col.data(), L.left_col.size() * 4));
             HIPCHK(hipMalloc(&ctx->d_u, T * 8));
             HIPCHK(hipMemset(ctx->d_u, 0, T * 8));
-            ctx->bytes_stored = (int64_t)L.fwd.size() * 2 + (int64_t)L.bwd.size() * 2 + (int64_t)L.coo.size() * 4 + (int64_t)L.far_tid.size() * 4 +
+            ctx->bytes_stored = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 + (int64_t)L.far_tid.size() * 4 +
                                 (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4 + (int64_t)L.left_ptr.size() * 8;
-            ctx->tl_fwd_slots = (int64_t)L.fwd.size(); ctx->tl_n_fslices = L.n_fslices;
-            std::vector<uint16_t>().swap(L.fwd); std::vector<uint16_t>().swap(L.bwd); std::vector<uint32_t>().swap(L.coo);
+            ctx->tl_fwd_slots = L.padded_slots; ctx->tl_n_fslices = L.n_fslices;
+            std::vector<uint32_t>().swap(L.fwd); std::vector<uint32_t>().swap(L.bwd); std::vector<uint32_t>().swap(L.coo);
             std::vector<int32_t>().swap(L.left_col);
             const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
 #define SETLDS_T(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
@@ -1338,8 +1349,8 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
         info_out->layout = EMSAR_LAYOUT_TILED | (L.merged ? EMSAR_LAYOUT_FLAG_MERGE_ROWS : 0);
         info_out->n_chunks = (int64_t)L.tiles.size();
         info_out->n_slices = L.n_fslices;
-        info_out->padded_entries = (int64_t)L.fwd.size(); info_out->far_entries = L.far_entries; info_out->window = emsar::kTileDict;
-        info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 2 + (int64_t)L.bwd.size() * 2 + (int64_t)L.coo.size() * 4 +
+        info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries; info_out->window = emsar::kTileDict;
+        info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 +
                                           (int64_t)L.far_tid.size() * 4 + (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4;
         info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
     }

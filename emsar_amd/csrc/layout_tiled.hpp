@@ -6,18 +6,18 @@
 //   * rows with ONE tid never reach the kernel: they are folded into a per-transcript count vector u
 //     (acc_t += u_t / theta_t is applied analytically in k_update);
 //   * rows with 2..kMaxRowLen tids are sorted by (block(min tid), length class, min tid) like the WINDOWED
-//     layout and cut into TILES of at most 2048 rows whose distinct tids fit a 1023-entry chunk-local
+//     layout and cut into TILES of at most 3072 rows whose distinct tids fit a 959-entry chunk-local
 //     DICTIONARY: the contiguous range [lo, lo+near_n) that covers most of the tile's tids plus an explicit list
-//     of far tids.  Every stored operand is the 16-bit byte offset (id*8) of a dictionary slot or of a row;
-//   * a tile has up to 4 SLICES of 512 rows; one wavefront owns one slice for the whole pass:
-//       forward index (E-step, row sums): column-major [k][512]; lane l owns rows 8l..8l+7, so column j of its
-//         rows is ONE int4 of eight 16-bit offsets; padding points at a zero slot (no branches);
-//       backward index (M-step, column sums) OF THE SAME 512 ROWS: for every dictionary column with >= 4 entries in
-//         the slice, its slice-local rows cut into segments of 7 row offsets headed by the column offset
-//         (8 x u16 = one int4).  Segments are dealt to lanes in contiguous column order (a lane keeps the running
+//     of far tids.  Every stored operand is a 10-BIT id (dictionary slot < 1024, slice row < 1024), three to a dword;
+//   * a tile has up to 4 SLICES of 768 rows; one wavefront owns one slice for the whole pass:
+//       forward index (E-step, row sums): column-major [k][768]; lane l owns rows 12l..12l+11, so column j of its
+//         rows is ONE int4 of twelve 10-bit ids; padding points at a zero slot (no branches);
+//       backward index (M-step, column sums) OF THE SAME 768 ROWS: for every dictionary column with >= 4 entries in
+//         the slice, its slice-local rows cut into segments of 11 row ids headed by the column id
+//         (12 x 10 bit = one int4).  Segments are dealt to lanes in contiguous column order (a lane keeps the running
 //         sum of a column in a register), but stored interleaved so that wave loads stay 1 KiB contiguous.
-//         Columns with < 4 entries go to a COO list of (column, row) offset pairs.
-//     Because the transposed index is per slice, the wave that computed w_r for its 512 rows is the only consumer
+//         Columns with < 4 entries go to a COO list of (column, row) id pairs.
+//     Because the transposed index is per slice, the wave that computed w_r for its 768 rows is the only consumer
 //     of them: E-step and M-step need no workgroup barrier in between;
 //   * rows longer than kMaxRowLen go to a leftover CSR processed by the generic kernel.
 #pragma once
@@ -32,18 +32,24 @@
 namespace emsar {
 
 constexpr int kTileSlices = 4;         // wavefronts per workgroup
-constexpr int kTileSliceRows = 512;    // 64 lanes x 8 rows
+constexpr int kRowsPerLane = 12;       // twelve 10-bit ids per int4
+constexpr int kTileSliceRows = 64 * kRowsPerLane;   // 768
 constexpr int kTileRows = kTileSlices * kTileSliceRows;
 constexpr int kTileDict = 959;         // theta + acc windows in LDS: 2 x 7.5 KiB; +1 zero slot (5 workgroups per CU)
 constexpr int kMaxRowLen = 768;        // longer rows -> leftover CSR (a row must fit one dictionary)
-constexpr int kSegRows = 7;            // row offsets per backward segment (plus 1 header = 8 x u16 = one int4)
+constexpr int kSegRows = 11;           // row ids per backward segment (plus 1 header = 12 x 10 bit = one int4)
+constexpr int kSliceDwords = kTileSliceRows / 3;    // dwords per forward column of a slice (256 = 1 KiB)
+
+// field i (0..11) of a packed int4: dword i/3, bits 10*(i%3) .. +10
+inline void pack10(uint32_t *q, int i, uint32_t id) { q[i / 3] |= (id & 0x3FFu) << (10 * (i % 3)); }
+inline uint32_t unpack10(const uint32_t *q, int i) { return (q[i / 3] >> (10 * (i % 3))) & 0x3FFu; }
 constexpr int kDenseMin = 4;           // columns with fewer entries in a slice use the COO list
 constexpr int64_t kTileEntries = 65536;
 
 struct Tile {                // 64 bytes
     uint64_t fwd_off;        // byte offset into fwd (multiple of 1024)
     uint64_t bwd_off;        // byte offset into bwd (multiple of 1024)
-    uint32_t row_base;       // first row slot of the tile (multiple of 512); slot = row_base + slice*512 + 8*lane + i
+    uint32_t row_base;       // first row slot of the tile (multiple of 768); slot = row_base + slice*768 + 12*lane + i
     uint32_t far_off;        // index of the tile's first far tid in far_tid[]
     uint32_t coo_off;        // index of the tile's first pair in coo[]
     int32_t lo;              // dictionary slot d < near_n  <->  tid lo + d
@@ -68,14 +74,14 @@ struct TiledLayout {
     bool merged = false;                // identical rows were merged: a slot stands for mem_row[mem_ptr[id] .. mem_ptr[id+1])
     std::vector<uint64_t> mem_ptr;
     std::vector<uint32_t> mem_row;
-    std::vector<uint16_t> fwd, bwd;
-    std::vector<uint32_t> coo;          // (col_off << 16) | row_off
+    std::vector<uint32_t> fwd, bwd;     // packed 10-bit ids
+    std::vector<uint32_t> coo;          // (col_id << 16) | row_id
     std::vector<int32_t> far_tid;
     // leftover rows (too long for a tile): plain CSR + original row ids
     std::vector<uint64_t> left_ptr;
     std::vector<int32_t> left_col;
     std::vector<uint32_t> left_row;
-    int64_t tiled_entries = 0, far_entries = 0, coo_entries = 0, n_fslices = 0;
+    int64_t tiled_entries = 0, far_entries = 0, coo_entries = 0, n_fslices = 0, padded_slots = 0;
     int64_t n_slots() const { return (int64_t)slot_row.size(); }
 };
 
@@ -198,7 +204,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     std::vector<int32_t> distinct;
     std::vector<uint32_t> pairs, sorted;   // (col_local << 16) | row_in_slice
     std::vector<uint32_t> ccount, fill;
-    std::vector<uint16_t> segs;
+    std::vector<uint32_t> segs;            // 4 dwords per segment
     int64_t i0 = 0;
     int32_t tile_id = 0;
     while (i0 < n_act) {
@@ -246,24 +252,27 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             else { loc[(size_t)t] = near_n + (int32_t)(out.far_tid.size() - T.far_off); out.far_tid.push_back(t); }
         }
         const int nd = near_n + far_n;
-        const uint16_t zero_off = (uint16_t)(nd * 8);
-        const uint16_t pad_row_off = (uint16_t)(kTileSliceRows * 8);   // w_r[512] of every slice = 0
+        const uint32_t zero_id = (uint32_t)nd;                         // th_w[nd] = 0
+        const uint32_t pad_row = (uint32_t)kTileSliceRows;             // w_r[768] of every slice = 0
         const int64_t nrow = i1 - i0;
         T.n_slices = (uint16_t)((nrow + kTileSliceRows - 1) / kTileSliceRows);
         T.row_base = (uint32_t)out.slot_row.size();
         out.slot_row.resize(out.slot_row.size() + (size_t)T.n_slices * kTileSliceRows, -1);
-        T.fwd_off = (uint64_t)out.fwd.size() * 2;
-        T.bwd_off = (uint64_t)out.bwd.size() * 2;
+        T.fwd_off = (uint64_t)out.fwd.size() * 4;
+        T.bwd_off = (uint64_t)out.bwd.size() * 4;
         T.coo_off = (uint32_t)out.coo.size();
         out.n_fslices += T.n_slices;
-        // 3. forward slices (all of them first: the tile's forward block is contiguous)
+        // 3. forward slices (all of them first: the tile's forward block is contiguous).  Column j of a slice is 256
+        //    dwords; row i of the slice is field i%12 of the int4 of lane i/12
+        uint32_t zero_dword = zero_id | (zero_id << 10) | (zero_id << 20);
         for (int s = 0; s < T.n_slices; s++) {
             int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
             int64_t k = 0;
             for (int64_t i = a0; i < bnd; i++) { uint32_t r = perm[(size_t)i]; k = std::max<int64_t>(k, (int64_t)(row_ptr[r + 1] - row_ptr[r])); }
             T.k[s] = (uint16_t)k;
             size_t base = out.fwd.size();
-            out.fwd.resize(base + (size_t)k * kTileSliceRows, zero_off);
+            out.fwd.resize(base + (size_t)k * kSliceDwords, zero_dword);
+            out.padded_slots += k * kTileSliceRows;
             for (int64_t i = a0; i < bnd; i++) {
                 uint32_t r = perm[(size_t)i];
                 uint32_t in_slice = (uint32_t)(i - a0);
@@ -271,7 +280,9 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 uint64_t b = row_ptr[r], e = row_ptr[r + 1];
                 for (uint64_t q = b; q < e; q++) {
                     int32_t d = loc[(size_t)col_idx[q]];
-                    out.fwd[base + (size_t)(q - b) * kTileSliceRows + in_slice] = (uint16_t)(d * 8);
+                    uint32_t *dw = &out.fwd[base + (size_t)(q - b) * kSliceDwords + in_slice / 3];
+                    const int sh = 10 * (int)(in_slice % 3);
+                    *dw = (*dw & ~(0x3FFu << sh)) | ((uint32_t)d << sh);
                     if (d >= near_n) out.far_entries++;
                 }
                 out.tiled_entries += (int64_t)(e - b);
@@ -297,28 +308,32 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             for (int d = 0; d < nd; d++) {
                 uint32_t b = ccount[(size_t)d], e = ccount[(size_t)d + 1];
                 if (e - b < (uint32_t)kDenseMin) {
-                    for (uint32_t q = b; q < e; q++) out.coo.push_back(((uint32_t)(d * 8) << 16) | (uint32_t)((sorted[q] & 0xFFFF) * 8));
+                    for (uint32_t q = b; q < e; q++) out.coo.push_back(((uint32_t)d << 16) | (sorted[q] & 0xFFFF));
                     continue;
                 }
                 for (uint32_t q = b; q < e; q += kSegRows) {
-                    segs.push_back((uint16_t)(d * 8));
-                    for (uint32_t j = 0; j < (uint32_t)kSegRows; j++)
-                        segs.push_back(q + j < e ? (uint16_t)((sorted[q + j] & 0xFFFF) * 8) : pad_row_off);
+                    uint32_t seg[4] = {0, 0, 0, 0};
+                    pack10(seg, 0, (uint32_t)d);
+                    for (uint32_t j = 0; j < (uint32_t)kSegRows; j++) pack10(seg, 1 + (int)j, q + j < e ? (sorted[q + j] & 0xFFFF) : pad_row);
+                    segs.insert(segs.end(), seg, seg + 4);
                 }
             }
             T.coo_n[s] = (uint16_t)(out.coo.size() - coo_before);
             out.coo_entries += T.coo_n[s];
-            const int64_t nseg = (int64_t)segs.size() / 8;
+            const int64_t nseg = (int64_t)segs.size() / 4;
             const int m = (int)((nseg + 63) / 64);
             T.m[s] = (uint16_t)m;
             size_t base = out.bwd.size();
-            out.bwd.resize(base + (size_t)m * 64 * 8, pad_row_off);
+            uint32_t empty[4] = {0, 0, 0, 0};                          // unused segment: zero column, padding rows
+            pack10(empty, 0, zero_id);
+            for (int j = 1; j < 12; j++) pack10(empty, j, pad_row);
+            out.bwd.resize(base + (size_t)m * 64 * 4);
             for (int64_t g = 0; g < (int64_t)m * 64; g++) {
                 // logical segment g -> lane g / m, unit g % m ; physical int4 index (unit*64 + lane)
                 int64_t lane = g / m, unit = g % m;
-                size_t u0 = base + (size_t)((unit * 64 + lane) * 8);
-                if (g < nseg) for (int w = 0; w < 8; w++) out.bwd[u0 + (size_t)w] = segs[(size_t)g * 8 + (size_t)w];
-                else out.bwd[u0] = zero_off;      // unused segment: zero column, padding rows
+                size_t u0 = base + (size_t)((unit * 64 + lane) * 4);
+                const uint32_t *src = g < nseg ? &segs[(size_t)g * 4] : empty;
+                for (int w = 0; w < 4; w++) out.bwd[u0 + (size_t)w] = src[w];
             }
         }
         out.tiles.push_back(T);
@@ -329,7 +344,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     // Largest tiles first: they start while the grid is full, the small ones fill the tail.
     auto work = [](const Tile &t) {
         int64_t w = 0;
-        for (int s = 0; s < t.n_slices; s++) w += (int64_t)t.k[s] * kTileSliceRows + (int64_t)t.m[s] * 64 * 8 + t.coo_n[s] * 2;
+        for (int s = 0; s < t.n_slices; s++) w += (int64_t)t.k[s] * kTileSliceRows + (int64_t)t.m[s] * 64 * 12 + t.coo_n[s] * 2;
         return w;
     };
     std::stable_sort(out.tiles.begin(), out.tiles.end(), [&](const Tile &a, const Tile &b) { return work(a) > work(b); });
@@ -356,14 +371,14 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
         const int nd = T.near_n + T.far_n;
         if (nd > kTileDict || T.n_slices > kTileSlices || T.row_base % kTileSliceRows) return -3;
         auto tid_of = [&](int d) { return d < T.near_n ? T.lo + d : L.far_tid[(size_t)T.far_off + (size_t)(d - T.near_n)]; };
-        size_t foff = (size_t)(T.fwd_off / 2), boff = (size_t)(T.bwd_off / 2), coff = T.coo_off;
+        size_t foff = (size_t)(T.fwd_off / 4), boff = (size_t)(T.bwd_off / 4), coff = T.coo_off;
         for (int s = 0; s < T.n_slices; s++) {
             pf.clear(); pb.clear();
             for (int i = 0; i < kTileSliceRows; i++) {
                 int64_t r = L.slot_row[(size_t)T.row_base + (size_t)s * kTileSliceRows + (size_t)i];
                 a.clear();
                 for (int j = 0; j < T.k[s]; j++) {
-                    int d = L.fwd[foff + (size_t)j * kTileSliceRows + (size_t)i] / 8;
+                    int d = (int)((L.fwd[foff + (size_t)j * kSliceDwords + (size_t)(i / 3)] >> (10 * (i % 3))) & 0x3FFu);
                     if (d > nd) return -4;
                     if (d == nd) continue;                        // zero slot = padding
                     a.push_back(tid_of(d));
@@ -387,23 +402,23 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
                 b.assign(col_idx + row_ptr[r], col_idx + row_ptr[r + 1]);
                 if (a != b) return -7;
             }
-            foff += (size_t)T.k[s] * kTileSliceRows;
+            foff += (size_t)T.k[s] * kSliceDwords;
             const int m = T.m[s];
             for (int64_t g = 0; g < (int64_t)m * 64; g++) {
                 int64_t lane = g / m, unit = g % m;
-                size_t u0 = boff + (size_t)((unit * 64 + lane) * 8);
-                uint32_t d = L.bwd[u0] / 8u;
-                for (int w = 1; w < 8; w++) {
-                    uint32_t rl = L.bwd[u0 + (size_t)w] / 8u;
+                const uint32_t *q = &L.bwd[boff + (size_t)((unit * 64 + lane) * 4)];
+                uint32_t d = unpack10(q, 0);
+                for (int w = 1; w < 12; w++) {
+                    uint32_t rl = unpack10(q, w);
                     if (rl == (uint32_t)kTileSliceRows) continue;
                     if (rl > (uint32_t)kTileSliceRows || d >= (uint32_t)nd) return -8;
                     pb.push_back((d << 16) | rl);
                 }
             }
-            boff += (size_t)m * 64 * 8;
+            boff += (size_t)m * 64 * 4;
             for (uint32_t q = 0; q < T.coo_n[s]; q++) {
                 uint32_t p = L.coo[coff + q];
-                pb.push_back((((p >> 16) / 8u) << 16) | ((p & 0xFFFF) / 8u));
+                pb.push_back(p);
             }
             coff += T.coo_n[s];
             std::sort(pf.begin(), pf.end()); std::sort(pb.begin(), pb.end());
