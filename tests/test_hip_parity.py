@@ -147,9 +147,9 @@ def test_error_paths(dev):
     assert e.value.status == -2
 
 
-@pytest.mark.parametrize("name,scale", [("cfg2", 0.05), ("cfg3", 0.004)])
+@pytest.mark.parametrize("name,scale", [("cfg2", 0.05), ("cfg3", 0.004), ("cfg5", 0.0005)])
 def test_synthetic_read_level_matches_oracle(dev, name, scale):
-    s = synth.make_config(name, scale)
+    s = synth.make_config(name, scale)                          # cfg5: heavy repeats, rows of 50-100 tids
     m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
     den = s["den"]
     th0 = np.ones(s["n_tx"])
