@@ -362,7 +362,10 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
     for (size_t i = 0; i < L.left_row.size(); i++) {
         uint32_t r = L.left_row[i];
         uint64_t n = L.left_ptr[i + 1] - L.left_ptr[i];
-        if (seen[r] || row_ptr[r + 1] - row_ptr[r] != n || std::memcmp(col_idx + row_ptr[r], L.left_col.data() + L.left_ptr[i], n * 4) != 0) return -2;
+        if (seen[r] || row_ptr[r + 1] - row_ptr[r] != n) return -2;
+        std::vector<int32_t> x(col_idx + row_ptr[r], col_idx + row_ptr[r + 1]), y(L.left_col.begin() + (int64_t)L.left_ptr[i], L.left_col.begin() + (int64_t)L.left_ptr[i + 1]);
+        if (L.merged) std::sort(x.begin(), x.end());          // the merged view keeps every row's tids sorted
+        if (x != y) return -2;
         seen[r] = 1;
     }
     std::vector<int32_t> a, b;
