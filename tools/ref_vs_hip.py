@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""End-to-end drop-in comparison on one box: the compiled reference (oracle/_ref/emsar, CPU) against emsar-hip (GPU)
+on the same synthetic rsh + default-bowtie input.  Prints wall times of both programs and the FPKM agreement.
+
+    python tools/ref_vs_hip.py [n_tx] [n_reads] [threads]
+
+The reference binary is test infrastructure (built in the build container from /root/reference by oracle/Makefile and
+shipped as a binary); it is used here only as the thing to compare against.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import numpy as np
+
+import make_golden as G
+import oracle as O
+
+n_tx = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 150000
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+REF = os.path.join(ROOT, "oracle", "_ref", "emsar")
+HIP = os.path.join(ROOT, "emsar_amd", "emsar-hip")
+
+with tempfile.TemporaryDirectory() as d:
+    # reuse the fixture generator for the inputs only (its reference runs are skipped by stubbing run_reference)
+    G.run_reference = lambda *a, **k: ["-"]
+    G.gzip_inplace = lambda p: None
+    G.synth_rsh_case(d, seed=77, n_tx=n_tx, minfrag=50, maxfrag=52, n_reads=n_reads, opts=[], with_quirks=False)
+    rsh, aln = os.path.join(d, "index.rsh"), os.path.join(d, "reads.bowtie")
+    print("input: %d transcripts, %d reads, bowtie text %.1f MB" % (n_tx, n_reads, os.path.getsize(aln) / 1e6), flush=True)
+    res = {}
+    for name, cmd in (("reference -p 1", [REF, "-q", "-p", "1", "-I", rsh, os.path.join(d, "r1"), "o", aln]),
+                      ("reference -p %d" % threads, [REF, "-q", "-p", str(threads), "-I", rsh, os.path.join(d, "rp"), "o", aln]),
+                      ("emsar-hip", [HIP, "-q", "--stats-json", os.path.join(d, "st.json"), "-I", rsh, os.path.join(d, "h"), "o", aln])):
+        t0 = time.time()
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        res[name] = time.time() - t0
+        print("%-18s %8.2f s wall (whole program: parse + model + solve + output)" % (name, res[name]), flush=True)
+    import json
+    st = json.load(open(os.path.join(d, "st.json")))["per_sample"][0]
+    print("emsar-hip breakdown: parse %.2f s, solve %.3f s (%d EM passes, converged %d)" % (st["parse_s"], st["solve_ms"] / 1e3, st["em_passes"], st["converged"]))
+    a = O.read_fpkm(os.path.join(d, "r1", "o.0.fpkm"))["fpkm"]
+    b = O.read_fpkm(os.path.join(d, "rp", "o.0.fpkm"))["fpkm"]
+    h = O.read_fpkm(os.path.join(d, "h", "o.0.fpkm"))["fpkm"]
+    tol = lambda x: 1e-5 * np.abs(x) + 1.5e-6
+    print("transcripts with FPKM > 0 (reference):", int((a > 0).sum()))
+    print("reference -p1 vs -p%d : %d transcripts differ beyond 1e-5 rel + 1.5e-6 (its own noise)" % (threads, int((np.abs(a - b) > tol(a)).sum())))
+    print("emsar-hip vs reference: %d transcripts differ beyond 1e-5 rel + 1.5e-6; max rel diff on FPKM > 1: %.2e"
+          % (int((np.abs(h - a) > tol(a)).sum()), float((np.abs(h - a) / np.maximum(a, 1e-300))[a > 1].max())))
