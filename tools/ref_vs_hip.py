@@ -2,7 +2,7 @@
 """End-to-end drop-in comparison on one box: the compiled reference (oracle/_ref/emsar, CPU) against emsar-hip (GPU)
 on the same synthetic rsh + default-bowtie input.  Prints wall times of both programs and the FPKM agreement.
 
-    python tools/ref_vs_hip.py [n_tx] [n_reads] [threads]
+    python tools/ref_vs_hip.py [n_tx] [n_reads] [threads] [largest_family]
 
 The reference binary is test infrastructure (built in the build container from /root/reference by oracle/Makefile and
 shipped as a binary); it is used here only as the thing to compare against.
@@ -24,6 +24,7 @@ import oracle as O
 n_tx = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 150000
 threads = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+fam_max = int(sys.argv[4]) if len(sys.argv) > 4 else 6          # largest gene family: the reference's cost is quadratic in it
 REF = os.path.join(ROOT, "oracle", "_ref", "emsar")
 HIP = os.path.join(ROOT, "emsar_amd", "emsar-hip")
 
@@ -31,7 +32,7 @@ with tempfile.TemporaryDirectory() as d:
     # reuse the fixture generator for the inputs only (its reference runs are skipped by stubbing run_reference)
     G.run_reference = lambda *a, **k: ["-"]
     G.gzip_inplace = lambda p: None
-    G.synth_rsh_case(d, seed=77, n_tx=n_tx, minfrag=50, maxfrag=52, n_reads=n_reads, opts=[], with_quirks=False)
+    G.synth_rsh_case(d, seed=77, n_tx=n_tx, minfrag=50, maxfrag=52, n_reads=n_reads, opts=[], fam_max=fam_max, with_quirks=False)
     rsh, aln = os.path.join(d, "index.rsh"), os.path.join(d, "reads.bowtie")
     print("input: %d transcripts, %d reads, bowtie text %.1f MB" % (n_tx, n_reads, os.path.getsize(aln) / 1e6), flush=True)
     res = {}
