@@ -47,7 +47,7 @@ def _run(cmd, cwd=None):
 
 def build_hip(force=False):
     src = os.path.join(CSRC, "emsar_hip.hip")
-    deps = [src, os.path.join(CSRC, "layout.hpp"), os.path.join(CSRC, "layout_tiled.hpp"), os.path.join(ROOT, "include", "emsar_hip.h")]
+    deps = [src, os.path.join(CSRC, "layout.hpp"), os.path.join(CSRC, "layout_tiled.hpp"), os.path.join(CSRC, "sets.hpp"), os.path.join(ROOT, "include", "emsar_hip.h")]
     if force or _stale(HIP_SO, deps):
         os.makedirs(BUILD, exist_ok=True)
         # compile inside build/ so that -save-temps leaves the .s (register / LDS usage) there

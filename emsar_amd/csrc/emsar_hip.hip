@@ -27,6 +27,7 @@
 #include "../../include/emsar_hip.h"
 #include "layout.hpp"
 #include "layout_tiled.hpp"
+#include "sets.hpp"
 
 namespace {
 
@@ -542,7 +543,8 @@ __global__ void k_fill_start(int n, const double *__restrict__ den, double *__re
 // grid-stride, one atomicMax per workgroup (hundreds of same-address atomics cost ~12 ns each)
 __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
                                                 const double *__restrict__ den, const double *__restrict__ u /* folded single-tid rows, may be null */,
-                                                double *__restrict__ th_out, double abs_floor, double count_floor, Scal *scal) {
+                                                double *__restrict__ th_out, double abs_floor, double count_floor, Scal *scal,
+                                                const uint8_t *__restrict__ kind /* non-null: only KIND_STREAMED transcripts enter the stopping rule */) {
     __shared__ double red[4];
     double d = 0.0;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
@@ -555,6 +557,7 @@ __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict_
         if (count_floor > 0.0 && dn > 0.0) fl = fmax(fl, count_floor / dn);    // floor expressed in inferred reads
         double dd = fabs(y - x) / (fabs(y) + fl);
         if (!(dd == dd)) dd = __builtin_huge_val();  // NaN -> +inf so that the host sees it
+        if (kind && kind[t] != emsar::KIND_STREAMED) dd = 0.0;
         d = fmax(d, dd);
     }
     for (int o = 32; o > 0; o >>= 1) d = fmax(d, __shfl_xor(d, o, 64));
@@ -636,6 +639,200 @@ __global__ __launch_bounds__(256) void k_sq_accept(int n, const double *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_solve_sets: the SET-RESIDENT solver.  One workgroup owns one connected set (sets.hpp) and runs the whole
+// SQUAREM-accelerated EM on it out of LDS: theta vectors, den, the folded single-row counts, the row weights and
+// the 16-bit CSR/CSC indices are loaded once, then every pass is two LDS sweeps (E-step over rows, M-step over
+// transcripts through the CSC -- no atomics, so the result is reproducible bit for bit) and a workgroup
+// reduction.  No global synchronisation, no kernel launch per pass: a pass costs ~1 us instead of the ~30 us
+// launch-latency floor of the streaming kernels, and every set stops at its own convergence.
+// Same update, same start (theta = 1 where den > 0), same stopping rule and the same likelihood-safeguarded S3
+// step as the streaming solve below, so both reach the same fixed point.
+// ------------------------------------------------------------------------------------------------
+struct SetStat { int32_t passes, converged; double delta; };
+struct SetSolveParams { double tol, abs_floor, count_floor; int32_t max_iter, accel; };
+
+template <int THREADS, int N>
+__device__ __forceinline__ void set_reduce_sum(double (&v)[N], double *red) {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = wave_sum(v[i]);
+    if (THREADS > 64) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();                       // red may still be read from the previous reduction
+        if (lane == 0)
+#pragma unroll
+            for (int i = 0; i < N; i++) red[wave * N + i] = v[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            double t = 0;
+            for (int w = 0; w < THREADS / 64; w++) t += red[w * N + i];
+            v[i] = t;
+        }
+    }
+}
+template <int THREADS>
+__device__ __forceinline__ double set_reduce_max(double v, double *red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    if (THREADS > 64) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        double t = 0;
+        for (int w = 0; w < THREADS / 64; w++) t = fmax(t, red[w]);
+        v = t;
+    }
+    return v;
+}
+
+struct SetLds {
+    double *den, *u, *w, *rw, *red;
+    const uint16_t *rp, *ent, *cp, *crow;
+    int nt, nr;
+};
+
+// E-step over the rows at x, then M-step: y = (x*acc + u)/den.  Returns this thread's share of sum R log S (+ the
+// folded single rows' u log x) when LL.
+template <int THREADS, bool LL>
+__device__ __forceinline__ double set_em_estep(const SetLds &L, const double *x) {
+    double ll = 0.0;
+    for (int j = threadIdx.x; j < L.nr; j += THREADS) {
+        double S = 0.0;
+        const int b = L.rp[j], e = L.rp[j + 1];
+        for (int k = b; k < e; k++) S += x[L.ent[k]];
+        const double r = L.rw[j];
+        const bool live = S > 0.0;
+        L.w[j] = live ? r / S : 0.0;
+        if (LL && live) ll += r * log(S);
+    }
+    __syncthreads();
+    return ll;
+}
+__device__ __forceinline__ double set_em_acc(const SetLds &L, int i) {
+    double a = 0.0;
+    const int b = L.cp[i], e = L.cp[i + 1];
+    for (int k = b; k < e; k++) a += L.w[L.crow[k]];
+    return a;
+}
+__device__ __forceinline__ double set_em_update(double x, double a, double u, double dn) {
+    return dn > 0.0 ? (x > 0.0 ? (x * a + u) / dn : 0.0) : 0.0;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__restrict__ desc, const int32_t *__restrict__ g_tid,
+                                                        const double *__restrict__ g_u, const double *__restrict__ row_w,
+                                                        const uint16_t *__restrict__ rp_g, const uint16_t *__restrict__ ent_g,
+                                                        const uint16_t *__restrict__ cp_g, const uint16_t *__restrict__ crow_g,
+                                                        const double *__restrict__ den_g, double *__restrict__ theta_g,
+                                                        SetStat *__restrict__ stat, SetSolveParams P) {
+    extern __shared__ double smem[];
+    const emsar::SetDesc d = desc[blockIdx.x];
+    const int nt = (int)d.n_t, nr = (int)d.n_r, nnz = (int)d.nnz;
+    double *A = smem, *B = A + nt, *Cc = B + nt;
+    SetLds L;
+    L.den = Cc + nt; L.u = L.den + nt; L.w = L.u + nt; L.rw = L.w + nr; L.red = L.rw + nr;
+    uint16_t *rp = (uint16_t *)(L.red + emsar::kSetRedDoubles), *ent = rp + (nr + 1), *cp = ent + nnz, *crow = cp + (nt + 1);
+    L.rp = rp; L.ent = ent; L.cp = cp; L.crow = crow; L.nt = nt; L.nr = nr;
+    for (int i = threadIdx.x; i < nt; i += THREADS) {
+        const double dn = den_g[g_tid[d.tid_off + i]];
+        L.den[i] = dn; L.u[i] = g_u[d.tid_off + i];
+        A[i] = dn > 0.0 ? 1.0 : 0.0;
+    }
+    for (int j = threadIdx.x; j < nr; j += THREADS) L.rw[j] = row_w[d.row_off + j];
+    for (int j = threadIdx.x; j <= nr; j += THREADS) rp[j] = rp_g[d.rp_off + j];
+    for (int i = threadIdx.x; i <= nt; i += THREADS) cp[i] = cp_g[d.cp_off + i];
+    for (int k = threadIdx.x; k < nnz; k += THREADS) { ent[k] = ent_g[d.ent_off + k]; crow[k] = crow_g[d.ent_off + k]; }
+    __syncthreads();
+
+    double stepmax = 1.0, delta = __builtin_huge_val();
+    int passes = 0, converged = 0;
+    double *res = A;
+    for (;;) {
+        // pass 1 (plain): B = EM(A); the stopping rule is measured on this step only
+        (void)set_em_estep<THREADS, false>(L, A);
+        double dloc = 0.0;
+        for (int i = threadIdx.x; i < nt; i += THREADS) {
+            const double x = A[i], dn = L.den[i];
+            const double y = set_em_update(x, set_em_acc(L, i), L.u[i], dn);
+            B[i] = y;
+            double fl = P.abs_floor;
+            if (P.count_floor > 0.0 && dn > 0.0) fl = fmax(fl, P.count_floor / dn);
+            double dd = fabs(y - x) / (fabs(y) + fl);
+            if (!(dd == dd)) dd = __builtin_huge_val();
+            dloc = fmax(dloc, dd);
+        }
+        delta = set_reduce_max<THREADS>(dloc, L.red);
+        __syncthreads();
+        passes++;
+        res = B;
+        if (delta < P.tol) { converged = 1; break; }
+        if (passes >= P.max_iter || delta == __builtin_huge_val()) break;
+        if (!P.accel) { double *t = A; A = B; B = t; continue; }
+        // pass 2: C = EM(B) with F(B); r = B-A, v = (C-B)-r
+        double s4[4];
+        s4[0] = set_em_estep<THREADS, true>(L, B);
+        s4[1] = s4[2] = s4[3] = 0.0;
+        for (int i = threadIdx.x; i < nt; i += THREADS) {
+            const double x = B[i], dn = L.den[i], u = L.u[i];
+            const double y = set_em_update(x, set_em_acc(L, i), u, dn);
+            Cc[i] = y;
+            if (u > 0.0 && x > 0.0) s4[0] += u * log(x);
+            s4[1] += x * dn;
+            const double r = x - A[i], v = (y - x) - r;
+            s4[2] += r * r; s4[3] += v * v;
+        }
+        set_reduce_sum<THREADS, 4>(s4, L.red);
+        const double F1 = s4[0] - s4[1];
+        double s = s4[3] > 0.0 ? sqrt(s4[2] / s4[3]) : 1.0;
+        s = fmin(fmax(s, 1.0), stepmax);
+        const bool extrap = s > 1.01;
+        // extrapolated point, in place of B
+        double s2[2] = {0.0, 0.0};
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt; i += THREADS) {
+            const double x2 = Cc[i];
+            double x = x2;
+            if (extrap) {
+                const double r = B[i] - A[i], v = (x2 - B[i]) - r;
+                const double y = A[i] + 2.0 * s * r + s * s * v;
+                x = (y > 0.0 && x2 > 0.0) ? y : x2;
+            }
+            B[i] = x;
+            s2[1] += x * L.den[i];
+        }
+        __syncthreads();
+        // pass 3: A = EM(B) with F(B)
+        s2[0] = set_em_estep<THREADS, true>(L, B);
+        for (int i = threadIdx.x; i < nt; i += THREADS) {
+            const double x = B[i], u = L.u[i];
+            A[i] = set_em_update(x, set_em_acc(L, i), u, L.den[i]);
+            if (u > 0.0 && x > 0.0) s2[0] += u * log(x);
+        }
+        set_reduce_sum<THREADS, 2>(s2, L.red);
+        const bool ok = !extrap || (s2[0] - s2[1] >= F1);
+        __syncthreads();
+        if (!ok) {
+            for (int i = threadIdx.x; i < nt; i += THREADS) A[i] = Cc[i];
+            if (s >= stepmax) stepmax = fmax(1.0, stepmax / 4.0);
+        }
+        if ((ok ? s : 1.0) >= stepmax) stepmax *= 4.0;
+        __syncthreads();
+        passes += 2;
+        res = A;
+        if (passes >= P.max_iter) break;
+    }
+    for (int i = threadIdx.x; i < nt; i += THREADS) theta_g[g_tid[d.tid_off + i]] = res[i];
+    if (threadIdx.x == 0) { stat[blockIdx.x].passes = passes; stat[blockIdx.x].converged = converged; stat[blockIdx.x].delta = delta; }
+}
+
+// transcripts outside every multi-transcript set: theta = (reads of its single-transcript rows) / den
+__global__ void k_closed_form(int n, const uint8_t *__restrict__ kind, const double *__restrict__ usum,
+                              const double *__restrict__ den, double *__restrict__ theta) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && kind[t] == emsar::KIND_CLOSED) theta[t] = den[t] > 0.0 ? usum[t] / den[t] : 0.0;
+}
+
 __global__ __launch_bounds__(256) void k_sum(int n, const double *__restrict__ x, double *out) {
     __shared__ double red[4];
     int t = blockIdx.x * 256 + threadIdx.x;
@@ -669,7 +866,7 @@ __global__ void k_normalise(int n, const double *__restrict__ mean, const double
 struct emsar_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     std::string err;
     // structure
     bool have_structure = false, have_sample = false;
@@ -710,6 +907,18 @@ struct emsar_hip_ctx {
     int64_t bytes_formula = 0, bytes_stored = 0;
     int64_t tl_fwd_slots = 0, tl_n_fslices = 0;
     double count_floor = 0.0;    // stopping-rule floor in reads for the current solve (emsar_em_params.count_floor)
+    const uint8_t *delta_mask = nullptr;   // d_kind while the streaming solve runs next to resident sets
+    // set-resident solver (sets.hpp): host copy of the CSR and of the sample's row weights, built lazily by solve
+    std::vector<uint64_t> h_row_ptr;
+    std::vector<int32_t> h_col, h_wgt;
+    bool sets_ready = false;
+    emsar::ResidentSets RS;      // index vectors are freed after the upload, counters stay
+    emsar::SetDesc *d_sdesc[emsar::kSetClasses] = {nullptr, nullptr, nullptr};
+    SetStat *d_sstat = nullptr; SetStat *h_sstat = nullptr; int64_t n_sstat = 0;
+    int32_t *d_g_tid = nullptr; double *d_g_u = nullptr, *d_row_w = nullptr, *d_usum = nullptr;
+    uint16_t *d_srp = nullptr, *d_sent = nullptr, *d_scp = nullptr, *d_scrow = nullptr;
+    uint8_t *d_kind = nullptr;
+    double sets_build_ms = 0.0;
 };
 
 namespace {
@@ -733,7 +942,20 @@ inline int64_t stored_bytes(const emsar_hip_ctx *ctx) {
     return ctx->bytes_stored + (ctx->weighted ? 4 * rows : 0) + (ctx->layout == EMSAR_LAYOUT_TILED ? 40 : 32) * (int64_t)ctx->n_tx;
 }
 
+void free_sets(emsar_hip_ctx *ctx) {
+    for (auto &p : ctx->d_sdesc) { dfree(p); p = nullptr; }
+    dfree(ctx->d_sstat); ctx->d_sstat = nullptr;
+    if (ctx->h_sstat) { (void)hipHostFree(ctx->h_sstat); ctx->h_sstat = nullptr; }
+    dfree(ctx->d_g_tid); dfree(ctx->d_g_u); dfree(ctx->d_row_w); dfree(ctx->d_usum);
+    dfree(ctx->d_srp); dfree(ctx->d_sent); dfree(ctx->d_scp); dfree(ctx->d_scrow); dfree(ctx->d_kind);
+    ctx->d_g_tid = nullptr; ctx->d_g_u = ctx->d_row_w = ctx->d_usum = nullptr;
+    ctx->d_srp = ctx->d_sent = ctx->d_scp = ctx->d_scrow = nullptr; ctx->d_kind = nullptr;
+    ctx->RS = emsar::ResidentSets(); ctx->sets_ready = false; ctx->n_sstat = 0;
+}
+
 void free_structure(emsar_hip_ctx *ctx) {
+    free_sets(ctx);
+    std::vector<uint64_t>().swap(ctx->h_row_ptr); std::vector<int32_t>().swap(ctx->h_col); std::vector<int32_t>().swap(ctx->h_wgt);
     dfree(ctx->d_row_ptr); dfree(ctx->d_col); dfree(ctx->d_chunks); dfree(ctx->d_slice_off); dfree(ctx->d_ent);
     ctx->d_row_ptr = nullptr; ctx->d_col = nullptr; ctx->d_chunks = nullptr; ctx->d_slice_off = nullptr; ctx->d_ent = nullptr;
     dfree(ctx->d_wgt); dfree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
@@ -815,7 +1037,8 @@ int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_l
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot]);
     if (rc) return rc;
     hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
-                       ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->d_scal);
+                       ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->d_scal,
+                       ctx->delta_mask);
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
 }
@@ -863,6 +1086,67 @@ int scatter_rows(emsar_hip_ctx *ctx, const double *val_host, double *d_out) {
     return EMSAR_HIP_OK;
 }
 
+// find and pack the connected sets of the current sample (sets.hpp) and move the records to the device
+int ensure_sets(emsar_hip_ctx *ctx) {
+    if (ctx->sets_ready) return EMSAR_HIP_OK;
+    auto t0 = std::chrono::steady_clock::now();
+    auto &S = ctx->RS;
+    try {
+        emsar::build_sets(ctx->n_rows, ctx->n_tx, ctx->h_row_ptr.data(), ctx->h_col.data(), ctx->h_wgt.data(), S);
+    } catch (const std::bad_alloc &) { free_sets(ctx); return EMSAR_HIP_ERR_OOM; }
+    auto up = [&](void **dp, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dp, std::max<size_t>(bytes, 16));
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dp, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    HIPCHK(up((void **)&ctx->d_kind, S.kind.data(), S.kind.size()));
+    HIPCHK(up((void **)&ctx->d_usum, S.usum.data(), S.usum.size() * 8));
+    const int64_t n = S.n_resident();
+    if (n > 0) {
+        HIPCHK(up((void **)&ctx->d_g_tid, S.g_tid.data(), S.g_tid.size() * 4));
+        HIPCHK(up((void **)&ctx->d_g_u, S.g_u.data(), S.g_u.size() * 8));
+        HIPCHK(up((void **)&ctx->d_row_w, S.row_w.data(), S.row_w.size() * 8));
+        HIPCHK(up((void **)&ctx->d_srp, S.rp.data(), S.rp.size() * 2));
+        HIPCHK(up((void **)&ctx->d_sent, S.ent.data(), S.ent.size() * 2));
+        HIPCHK(up((void **)&ctx->d_scp, S.cp.data(), S.cp.size() * 2));
+        HIPCHK(up((void **)&ctx->d_scrow, S.crow.data(), S.crow.size() * 2));
+        for (int c = 0; c < emsar::kSetClasses; c++)
+            if (!S.desc[c].empty()) HIPCHK(up((void **)&ctx->d_sdesc[c], S.desc[c].data(), S.desc[c].size() * sizeof(emsar::SetDesc)));
+        HIPCHK(hipMalloc(&ctx->d_sstat, (size_t)n * sizeof(SetStat)));
+        HIPCHK(hipHostMalloc((void **)&ctx->h_sstat, (size_t)n * sizeof(SetStat), hipHostMallocDefault));
+        ctx->n_sstat = n;
+        HIPCHK(hipFuncSetAttribute((const void *)k_solve_sets<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)emsar::kSetLdsCap[0]));
+        HIPCHK(hipFuncSetAttribute((const void *)k_solve_sets<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)emsar::kSetLdsCap[1]));
+        HIPCHK(hipFuncSetAttribute((const void *)k_solve_sets<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)emsar::kSetLdsCap[2]));
+    }
+    // the device copies are the only ones needed from here on (desc sizes and counters stay)
+    std::vector<int32_t>().swap(S.g_tid); std::vector<double>().swap(S.g_u); std::vector<double>().swap(S.row_w);
+    std::vector<uint16_t>().swap(S.rp); std::vector<uint16_t>().swap(S.ent); std::vector<uint16_t>().swap(S.cp); std::vector<uint16_t>().swap(S.crow);
+    std::vector<double>().swap(S.usum);
+    ctx->sets_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->sets_ready = true;
+    return EMSAR_HIP_OK;
+}
+
+// closed-form transcripts and every LDS-resident set, written into theta (the streamed sets' entries are left alone)
+int solve_resident_sets(emsar_hip_ctx *ctx, const SetSolveParams &P, double *theta) {
+    const auto &S = ctx->RS;
+    hipLaunchKernelGGL(k_closed_form, dim3(grid_for(ctx->n_tx, 256)), dim3(256), 0, ctx->stream, ctx->n_tx, ctx->d_kind, ctx->d_usum,
+                       ctx->d_den, theta);
+    size_t off = 0;
+#define LAUNCH_S(C, TH)                                                                                                    \
+    if (!S.desc[C].empty()) {                                                                                              \
+        hipLaunchKernelGGL(k_solve_sets<TH>, dim3((unsigned)S.desc[C].size()), dim3(TH), S.max_lds[C], ctx->stream,          \
+                           ctx->d_sdesc[C], ctx->d_g_tid, ctx->d_g_u, ctx->d_row_w, ctx->d_srp, ctx->d_sent, ctx->d_scp,     \
+                           ctx->d_scrow, ctx->d_den, theta, ctx->d_sstat + off, P);                                        \
+        off += S.desc[C].size();                                                                                           \
+    }
+    LAUNCH_S(0, 64) LAUNCH_S(1, 256) LAUNCH_S(2, 512)
+#undef LAUNCH_S
+    HIPCHK(hipGetLastError());
+    return EMSAR_HIP_OK;
+}
+
 }  // namespace
 
 // ==================================================================================================
@@ -897,7 +1181,7 @@ int emsar_hip_create(emsar_hip_ctx **out, int device_id) {
     auto fail = [&](int rc) { emsar_hip_destroy(ctx); return rc; };
     if (hipSetDevice(device_id) != hipSuccess) return fail(EMSAR_HIP_ERR_NO_DEVICE);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
-    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipMalloc(&ctx->d_scal, sizeof(Scal)) != hipSuccess) return fail(EMSAR_HIP_ERR_OOM);
     if (hipHostMalloc((void **)&ctx->h_scal, sizeof(Scal), hipHostMallocDefault) != hipSuccess) return fail(EMSAR_HIP_ERR_OOM);
     // both pass kernels may need more than the default dynamic-LDS limit
@@ -914,6 +1198,7 @@ void emsar_hip_destroy(emsar_hip_ctx *ctx) {
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1006,6 +1291,10 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
         free_structure(ctx);
         return EMSAR_HIP_ERR_OOM;
     }
+    try {   // kept for the set-resident solver, which is built per sample (sets depend on which rows carry reads)
+        ctx->h_row_ptr.assign(row_ptr, row_ptr + n_rows + 1);
+        ctx->h_col.assign(col_idx, col_idx + ctx->nnz);
+    } catch (const std::bad_alloc &) { free_structure(ctx); return EMSAR_HIP_ERR_OOM; }
     HIPCHK(hipMalloc(&ctx->d_den, T * 8));
     HIPCHK(hipMalloc(&ctx->d_acc, T * 8));
     for (auto &p : ctx->d_th) HIPCHK(hipMalloc(&p, T * 8));
@@ -1037,6 +1326,11 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
         if (row_E && row_E[r] == 0.0) x = 0;
         return x;
     };
+    free_sets(ctx);
+    try {
+        ctx->h_wgt.resize((size_t)n_rows);
+        for (int64_t r = 0; r < n_rows; r++) ctx->h_wgt[(size_t)r] = weight_of(r);
+    } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
         const auto &L = ctx->TL;
         dfree(ctx->d_left_wgt); ctx->d_left_wgt = nullptr;
@@ -1141,6 +1435,7 @@ int emsar_hip_run_passes(emsar_hip_ctx *ctx, int32_t n_passes, float *elapsed_ms
     if (!ctx || n_passes < 0) return EMSAR_HIP_ERR_ARG;
     if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
     HIPCHK(hipSetDevice(ctx->device));
+    ctx->delta_mask = nullptr;
     hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int cur = 0;  // th[cur] holds the current point, th[cur^1] receives the next
@@ -1168,18 +1463,25 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     if (p.abs_floor <= 0) p.abs_floor = 1e-6;
     if (p.check_every <= 0) p.check_every = 8;
     if (!(p.count_floor >= 0.0)) return EMSAR_HIP_ERR_ARG;
+    if (p.set_mode != 0 && p.set_mode != 1) return EMSAR_HIP_ERR_ARG;
     ctx->count_floor = p.count_floor;
+    ctx->delta_mask = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    const bool use_sets = p.set_mode == 0;
+    if (use_sets && (rc = ensure_sets(ctx))) return rc;
+    // the streaming passes run when asked for, or for the sets that do not fit a workgroup
+    const bool need_stream = !use_sets || ctx->RS.n_streamed_sets > 0;
+    if (use_sets && need_stream) ctx->delta_mask = ctx->d_kind;
     auto t0 = std::chrono::steady_clock::now();
-    int rc = emsar_hip_reset_theta(ctx);
-    if (rc) return rc;
+    if ((rc = emsar_hip_reset_theta(ctx))) return rc;
     hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const int n = ctx->n_tx, g = grid_for(n, 256);
     double **th = ctx->d_th;  // 0:th0 1:th1 2:th2 3:thx 4:thn
-    int iters = 0, converged = 0, cycles = 0;
-    double delta = INFINITY;
-    while (iters < p.max_iter) {
+    int iters = 0, converged = need_stream ? 0 : 1, cycles = 0;
+    double delta = need_stream ? INFINITY : 0.0;
+    while (need_stream && iters < p.max_iter) {
         hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
         if (!p.accel) {
             if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor))) return rc;
@@ -1207,7 +1509,15 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
             if (delta < p.tol) { converged = 1; break; }
         }
     }
+    ctx->delta_mask = nullptr;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (use_sets) {
+        SetSolveParams P{p.tol, p.abs_floor, p.count_floor, p.max_iter, p.accel};
+        if ((rc = solve_resident_sets(ctx, P, th[0]))) return rc;
+        if (ctx->n_sstat > 0)
+            HIPCHK(hipMemcpyAsync(ctx->h_sstat, ctx->d_sstat, (size_t)ctx->n_sstat * sizeof(SetStat), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipEventRecord(ctx->ev2, ctx->stream));
     // F at the returned point: one likelihood-only pass (not counted in iters)
     hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
     if ((rc = launch_pass(ctx, MODE_EM_LL, th[0], ctx->d_acc, &ctx->d_scal->ll[0]))) return rc;
@@ -1219,17 +1529,38 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     ctx->count_floor = 0.0;
     for (int32_t t = 0; t < n; t++)
         if (!std::isfinite(fpkm_out[t])) { ctx->err = "non-finite theta"; return EMSAR_HIP_ERR_NUMERIC; }
+    int32_t set_max = 0, set_unconv = 0;
+    int64_t set_sum = 0;
+    if (use_sets)
+        for (int64_t i = 0; i < ctx->n_sstat; i++) {
+            const SetStat &q = ctx->h_sstat[i];
+            set_max = std::max(set_max, q.passes); set_sum += q.passes;
+            if (!q.converged) set_unconv++;
+            if (q.delta > delta) delta = q.delta;
+        }
+    if (set_unconv) converged = 0;
     if (stats) {
-        float ms = 0;
+        float ms = 0, ms_sets = 0;
         HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        stats->iters = iters;
+        HIPCHK(hipEventElapsedTime(&ms_sets, ctx->ev1, ctx->ev2));
+        memset(stats, 0, sizeof(*stats));
+        stats->iters = iters + set_max;
         stats->converged = converged;
         stats->final_delta = delta;
         stats->loglik = ctx->h_scal->ll[0] + ctx->loglik_const - ctx->h_scal->ll[3];
-        stats->kernel_ms = ms;
+        stats->kernel_ms = ms + (use_sets ? ms_sets : 0.0f);
         stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         stats->bytes_per_pass = ctx->bytes_formula;
         stats->stored_bytes_per_pass = stored_bytes(ctx);
+        if (use_sets) {
+            stats->sets_resident = (int32_t)ctx->RS.n_resident();
+            stats->sets_streamed = (int32_t)ctx->RS.n_streamed_sets;
+            stats->set_passes_max = set_max;
+            stats->sets_unconverged = set_unconv;
+            stats->set_passes_sum = set_sum;
+            stats->sets_build_ms = ctx->sets_build_ms;
+            stats->sets_kernel_ms = ms_sets;
+        }
     }
     return EMSAR_HIP_OK;
 }
@@ -1355,6 +1686,26 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
         info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
     }
     return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
+}
+
+int emsar_hip_sets_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
+                             const int32_t *row_weight, emsar_hip_sets_info *o) {
+    if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
+    if (row_weight) for (int64_t r = 0; r < n_rows; r++) if (row_weight[r] < 0) return EMSAR_HIP_ERR_ARG;
+    emsar::ResidentSets S;
+    try {
+        emsar::build_sets(n_rows, n_tx, row_ptr, col_idx, row_weight, S);
+    } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
+    int rc = emsar::check_sets(n_rows, n_tx, row_ptr, col_idx, row_weight, S);
+    if (o) {
+        memset(o, 0, sizeof(*o));
+        o->n_components = S.n_components;
+        for (int c = 0; c < emsar::kSetClasses; c++) { o->sets_resident[c] = (int64_t)S.desc[c].size(); o->max_lds_bytes[c] = (int64_t)S.max_lds[c]; }
+        o->sets_streamed = S.n_streamed_sets;
+        o->tids_closed = S.n_closed_tids; o->tids_resident = S.n_resident_tids; o->tids_streamed = S.n_streamed_tids;
+        o->rows_in = S.rows_in; o->rows_stored = S.rows_stored;
+    }
+    return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 200 + rc;
 }
 
 }  // extern "C"

@@ -36,7 +36,7 @@ typedef struct {
     const char *rsh_path, *outdir, *prefix;
     char **aln; int n_aln;
     emsar_aln_opts ao;
-    int n_round, delta, print_segments, verbose, accel;
+    int n_round, delta, print_segments, verbose, accel, set_mode;
     double tol, count_floor; int max_iter;
     const char *stats_json;
 } config;
@@ -82,7 +82,7 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i) {
     if (!theta || !mean || !sd || !ieuma || !tpm || !ir || !iri || !rounds) { rc = EMSAR_HOST_ERR_OOM; goto done; }
 
     /* ---- the replaced call: run_MLE_threads() + construct_FPKMfinal, emsar_main.c:444-450 ---- */
-    emsar_em_params p = {cfg->max_iter, cfg->accel, cfg->tol, 0.0, 0, 0, cfg->count_floor};
+    emsar_em_params p = {cfg->max_iter, cfg->accel, cfg->tol, 0.0, 0, cfg->set_mode, cfg->count_floor};
     if ((rc = emsar_hip_upload_sample(ctx, cnt->R, m->E_solver, NULL)) ||
         (rc = emsar_hip_solve(ctx, &p, theta, &w->stats[i]))) {
         fprintf(stderr, "alnfile[%d]: %s (%s)\n", i, emsar_hip_strerror(rc), emsar_hip_last_error(ctx));
@@ -151,6 +151,7 @@ static void usage(const char *a0) {
             "  -d, --delta <d>         10^d scaling of the effective lengths (default 0)\n"
             "  -g, --print_segments    also write .segments\n"
             "      --count-floor <reads> stopping-rule floor in inferred reads (default 0 = off; e.g. 1e-3 for large samples)\n"
+            "      --streaming-only      do not split the problem into connected sets (every pass streams the whole matrix)\n"
             "      --gpus <n> / --device <d> / --plain / --stats-json <file> / -q / -v\n", a0);
 }
 
@@ -165,7 +166,7 @@ int main(int argc, char **argv) {
         {"print_segments", no_argument, 0, 'g'}, {"multisample", no_argument, 0, 'M'}, {"SAM", no_argument, 0, 'S'}, {"BAM", no_argument, 0, 'B'},
         {"verbose", no_argument, 0, 'v'}, {"no_verbose", no_argument, 0, 'q'}, {"gpus", required_argument, 0, 1000},
         {"device", required_argument, 0, 1001}, {"plain", no_argument, 0, 1002}, {"stats-json", required_argument, 0, 1003},
-        {"count-floor", required_argument, 0, 1004},
+        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005},
         {"maxfraglen", required_argument, 0, 'F'}, {"minfraglen", required_argument, 0, 'f'}, {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "vqPs:p:F:f:n:e:d:gMSBk:i:I:", lo, NULL)) != -1) {
@@ -191,6 +192,7 @@ int main(int argc, char **argv) {
             case 1002: cfg.accel = 0; break;
             case 1003: cfg.stats_json = optarg; break;
             case 1004: cfg.count_floor = atof(optarg); if (cfg.count_floor < 0) { fprintf(stderr, "--count-floor must be >= 0.\n"); return 1; } break;
+            case 1005: cfg.set_mode = 1; break;
             default: usage(argv[0]); return 1;
         }
     }
@@ -256,9 +258,11 @@ int main(int argc, char **argv) {
         if (f) {
             fprintf(f, "{\"samples\": %d, \"gpus\": %d, \"wall_s\": %.6f, \"failed\": %d, \"per_sample\": [", n_list, n_workers, wall, bad);
             for (int i = 0; i < n_list; i++)
-                fprintf(f, "%s{\"status\": %d, \"parse_s\": %.6f, \"em_passes\": %d, \"converged\": %d, \"solve_ms\": %.4f, \"kernel_ms\": %.4f, \"loglik\": %.9g, \"bytes_per_pass\": %lld}",
+                fprintf(f, "%s{\"status\": %d, \"parse_s\": %.6f, \"em_passes\": %d, \"converged\": %d, \"solve_ms\": %.4f, \"kernel_ms\": %.4f, \"loglik\": %.9g, \"bytes_per_pass\": %lld, "
+                           "\"sets_resident\": %d, \"sets_streamed\": %d, \"set_passes_max\": %d, \"set_passes_sum\": %lld, \"sets_build_ms\": %.4f, \"sets_kernel_ms\": %.4f}",
                         i ? ", " : "", status[i], parse_s[i], stats[i].iters, stats[i].converged, stats[i].solve_ms, stats[i].kernel_ms, stats[i].loglik,
-                        (long long)stats[i].bytes_per_pass);
+                        (long long)stats[i].bytes_per_pass, stats[i].sets_resident, stats[i].sets_streamed, stats[i].set_passes_max,
+                        (long long)stats[i].set_passes_sum, stats[i].sets_build_ms, stats[i].sets_kernel_ms);
             fprintf(f, "]}\n");
             fclose(f);
         }

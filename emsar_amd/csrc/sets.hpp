@@ -1,0 +1,290 @@
+// sets.hpp -- host-side builder of the SET-RESIDENT solver's data (pure C++, no HIP: also compiled by the CPU
+// sanitizer harness tools/layout_fuzz.cpp).
+//
+// The reference maximises each connected set of segments on its own (run_MLE_threads hands out sids,
+// /root/reference/src/emsar_main.c:446-474; sets come from build_TC_from_CT_2/propagate_2,
+// emsar_functions.c:2201-2259).  The EM decouples the same way: theta_t is updated from the rows that contain t
+// only, and rows with R = 0 enter through den_t alone.  So the transcripts split into the connected components
+// of the rows with R > 0 (and E > 0) -- finer than the reference's sets, which also link through R = 0 rows --
+// and every component can be iterated to convergence independently.
+//
+//   * a component of one transcript has the closed form theta_t = (sum of its rows' R) / den_t;
+//   * a component whose working set fits the 160 KiB LDS of a CU is packed here into a self-contained record
+//     (local 16-bit ids, CSR for the E-step, CSC for the M-step, identical rows merged, single-transcript rows
+//     folded into a per-transcript count) and solved by ONE workgroup with no global synchronisation;
+//   * anything larger is left to the streaming kernels (kind 2).
+#ifndef EMSAR_SETS_HPP
+#define EMSAR_SETS_HPP
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+namespace emsar {
+
+struct SetDesc {                 // 32 bytes, read by the kernel
+    uint32_t tid_off;            // into g_tid / g_u
+    uint32_t row_off;            // into row_w
+    uint32_t ent_off;            // into ent / crow
+    uint32_t rp_off, cp_off;     // into rp (n_r + 1) / cp (n_t + 1)
+    uint32_t n_t, n_r, nnz;
+};
+
+constexpr int kSetClasses = 3;
+constexpr int kSetThreads[kSetClasses] = {64, 256, 512};
+constexpr size_t kSetLdsCap[kSetClasses] = {6 * 1024, 48 * 1024, 156 * 1024};
+constexpr int kSetRedDoubles = 64;   // LDS scratch of the workgroup reductions (4 values x 16 waves)
+
+// bytes of LDS one resident set needs: 5 transcript vectors (A, B, C, den, u), 2 row vectors (w, R), the
+// reduction scratch and the four 16-bit index arrays
+inline size_t set_lds_bytes(size_t n_t, size_t n_r, size_t nnz) {
+    size_t b = 8 * (5 * n_t + 2 * n_r + (size_t)kSetRedDoubles) + 2 * ((n_r + 1) + (n_t + 1) + 2 * nnz);
+    return (b + 15) & ~(size_t)15;
+}
+
+enum TidKind : uint8_t { KIND_CLOSED = 0, KIND_RESIDENT = 1, KIND_STREAMED = 2 };
+
+struct ResidentSets {
+    std::vector<SetDesc> desc[kSetClasses];
+    size_t max_lds[kSetClasses] = {0, 0, 0};
+    std::vector<int32_t> g_tid;
+    std::vector<double> g_u, row_w;
+    std::vector<uint16_t> rp, ent, cp, crow;
+    std::vector<uint8_t> kind;        // [n_tx]
+    std::vector<double> usum;         // [n_tx] sum of R over the rows whose only transcript is t
+    int64_t n_components = 0;         // with at least two transcripts
+    int64_t n_streamed_sets = 0, n_streamed_tids = 0, n_resident_tids = 0, n_closed_tids = 0;
+    int64_t rows_in = 0, rows_stored = 0;   // multi-transcript rows with weight before / after merging
+    int64_t n_resident() const { return (int64_t)(desc[0].size() + desc[1].size() + desc[2].size()); }
+};
+
+namespace detail {
+inline int32_t uf_find(std::vector<int32_t> &p, int32_t x) {
+    while (p[(size_t)x] != x) { p[(size_t)x] = p[(size_t)p[(size_t)x]]; x = p[(size_t)x]; }
+    return x;
+}
+}  // namespace detail
+
+// wgt[r] >= 0: weight of row r inside the likelihood (0 = the row does not couple anything).
+// Returns 0; the CSR is assumed validated (validate_csr).
+inline int build_sets(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx, const int32_t *wgt,
+                      ResidentSets &out) {
+    out = ResidentSets();
+    const size_t T = (size_t)n_tx;
+    out.kind.assign(T, KIND_CLOSED);
+    out.usum.assign(T, 0.0);
+    std::vector<int32_t> parent(T);
+    std::iota(parent.begin(), parent.end(), 0);
+    std::vector<int64_t> multi_rows;   // rows with weight and >= 2 distinct transcripts
+    for (int64_t r = 0; r < n_rows; r++) {
+        const int32_t x = wgt ? wgt[r] : 1;
+        const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+        if (x <= 0 || b == e) continue;
+        const int32_t first = col_idx[b];
+        bool single = true;
+        for (uint64_t k = b + 1; k < e; k++) if (col_idx[k] != first) { single = false; break; }
+        if (single) { out.usum[(size_t)first] += (double)x; continue; }
+        multi_rows.push_back(r);
+        int32_t ra = detail::uf_find(parent, first);
+        for (uint64_t k = b + 1; k < e; k++) {
+            int32_t rb = detail::uf_find(parent, col_idx[k]);
+            if (rb != ra) { if (rb < ra) std::swap(ra, rb); parent[(size_t)rb] = ra; }
+        }
+    }
+    out.rows_in = (int64_t)multi_rows.size();
+    // components with >= 2 transcripts, numbered by their smallest tid (the root: unions keep the smaller id)
+    std::vector<int32_t> comp_of(T, -1);
+    std::vector<int32_t> comp_nt;
+    for (size_t t = 0; t < T; t++) {
+        int32_t root = detail::uf_find(parent, (int32_t)t);
+        if ((size_t)root == t) continue;
+        if (comp_of[(size_t)root] < 0) { comp_of[(size_t)root] = (int32_t)comp_nt.size(); comp_nt.push_back(1); }
+        comp_of[t] = comp_of[(size_t)root];
+        comp_nt[(size_t)comp_of[t]]++;
+    }
+    const size_t NC = comp_nt.size();
+    out.n_components = (int64_t)NC;
+    if (NC == 0) { out.n_closed_tids = (int64_t)T; return 0; }
+    // bucket transcripts and rows by component (counting sort keeps tids ascending)
+    std::vector<uint64_t> tptr(NC + 1, 0), rptr(NC + 1, 0), nnz_of(NC, 0);
+    for (size_t c = 0; c < NC; c++) tptr[c + 1] = tptr[c] + (uint64_t)comp_nt[c];
+    std::vector<int32_t> tids(tptr[NC]);
+    {
+        std::vector<uint64_t> fill(tptr.begin(), tptr.end() - 1);
+        for (size_t t = 0; t < T; t++) if (comp_of[t] >= 0) tids[fill[(size_t)comp_of[t]]++] = (int32_t)t;
+    }
+    for (int64_t r : multi_rows) { size_t c = (size_t)comp_of[(size_t)col_idx[row_ptr[r]]]; rptr[c + 1]++; nnz_of[c] += row_ptr[r + 1] - row_ptr[r]; }
+    for (size_t c = 0; c < NC; c++) rptr[c + 1] += rptr[c];
+    std::vector<int64_t> rows(rptr[NC]);
+    {
+        std::vector<uint64_t> fill(rptr.begin(), rptr.end() - 1);
+        for (int64_t r : multi_rows) rows[fill[(size_t)comp_of[(size_t)col_idx[row_ptr[r]]]]++] = r;
+    }
+    std::vector<int64_t>().swap(multi_rows);
+    std::vector<int32_t> local(T, -1);
+    const size_t cap = kSetLdsCap[kSetClasses - 1];
+    std::vector<uint16_t> lst;            // local sorted tid lists of the component's rows, back to back
+    std::vector<uint32_t> lptr, order;
+    for (size_t c = 0; c < NC; c++) {
+        const size_t nt = (size_t)comp_nt[c];
+        const size_t nr0 = (size_t)(rptr[c + 1] - rptr[c]);
+        auto stream = [&]() {
+            for (uint64_t q = tptr[c]; q < tptr[c + 1]; q++) out.kind[(size_t)tids[q]] = KIND_STREAMED;
+            out.n_streamed_sets++; out.n_streamed_tids += (int64_t)nt;
+        };
+        // cheap bound first: even with every row merged away the transcript vectors must fit, and the local
+        // lists of a set worth packing are small
+        if (nt > 65535 || set_lds_bytes(nt, 1, 2) > cap || nnz_of[c] > (uint64_t)16 * 1024 * 1024) { stream(); continue; }
+        for (size_t i = 0; i < nt; i++) local[(size_t)tids[tptr[c] + i]] = (int32_t)i;
+        lst.clear(); lptr.assign(1, 0);
+        for (size_t j = 0; j < nr0; j++) {
+            const int64_t r = rows[rptr[c] + j];
+            const size_t at = lst.size();
+            for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) lst.push_back((uint16_t)local[(size_t)col_idx[k]]);
+            std::sort(lst.begin() + (ptrdiff_t)at, lst.end());
+            lptr.push_back((uint32_t)lst.size());
+        }
+        // merge identical rows: order rows by (length, list), add the weights of equal neighbours
+        order.resize(nr0);
+        std::iota(order.begin(), order.end(), 0u);
+        auto cmp3 = [&](uint32_t a, uint32_t b) -> int {
+            const uint32_t la = lptr[a + 1] - lptr[a], lb = lptr[b + 1] - lptr[b];
+            if (la != lb) return la < lb ? -1 : 1;
+            for (uint32_t k = 0; k < la; k++) {
+                const uint16_t x = lst[lptr[a] + k], y = lst[lptr[b] + k];
+                if (x != y) return x < y ? -1 : 1;
+            }
+            return 0;
+        };
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { int q = cmp3(a, b); return q ? q < 0 : a < b; });
+        std::vector<uint32_t> rep;        // representative (first) row of each distinct list
+        std::vector<double> repw;
+        size_t nnz = 0;
+        for (size_t j = 0; j < nr0; j++) {
+            const uint32_t a = order[j];
+            const double x = (double)(wgt ? wgt[rows[rptr[c] + a]] : 1);
+            if (!rep.empty() && cmp3(rep.back(), a) == 0) { repw.back() += x; continue; }
+            rep.push_back(a); repw.push_back(x);
+            nnz += lptr[a + 1] - lptr[a];
+        }
+        const size_t nr = rep.size();
+        const size_t bytes = set_lds_bytes(nt, nr, nnz);
+        if (bytes > cap || nr > 65535 || nnz > 65535) {
+            for (size_t i = 0; i < nt; i++) local[(size_t)tids[tptr[c] + i]] = -1;
+            stream();
+            continue;
+        }
+        int cls = 0;
+        while (bytes > kSetLdsCap[cls]) cls++;
+        SetDesc d;
+        d.tid_off = (uint32_t)out.g_tid.size(); d.row_off = (uint32_t)out.row_w.size(); d.ent_off = (uint32_t)out.ent.size();
+        d.rp_off = (uint32_t)out.rp.size(); d.cp_off = (uint32_t)out.cp.size();
+        d.n_t = (uint32_t)nt; d.n_r = (uint32_t)nr; d.nnz = (uint32_t)nnz;
+        std::vector<uint32_t> cnt(nt + 1, 0);
+        uint32_t pos = 0;
+        for (size_t j = 0; j < nr; j++) {
+            out.rp.push_back((uint16_t)pos);
+            out.row_w.push_back(repw[j]);
+            for (uint32_t k = lptr[rep[j]]; k < lptr[rep[j] + 1]; k++) { out.ent.push_back(lst[k]); cnt[(size_t)lst[k] + 1]++; pos++; }
+        }
+        out.rp.push_back((uint16_t)pos);
+        for (size_t i = 0; i < nt; i++) cnt[i + 1] += cnt[i];
+        for (size_t i = 0; i <= nt; i++) out.cp.push_back((uint16_t)cnt[i]);
+        out.crow.resize(out.ent.size());
+        {
+            std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
+            for (size_t j = 0; j < nr; j++)
+                for (uint32_t k = lptr[rep[j]]; k < lptr[rep[j] + 1]; k++) out.crow[d.ent_off + fill[(size_t)lst[k]]++] = (uint16_t)j;
+        }
+        for (size_t i = 0; i < nt; i++) {
+            const int32_t t = tids[tptr[c] + i];
+            out.g_tid.push_back(t);
+            out.g_u.push_back(out.usum[(size_t)t]);
+            out.kind[(size_t)t] = KIND_RESIDENT;
+            local[(size_t)t] = -1;
+        }
+        out.desc[cls].push_back(d);
+        out.max_lds[cls] = std::max(out.max_lds[cls], bytes);
+        out.n_resident_tids += (int64_t)nt;
+        out.rows_stored += (int64_t)nr;
+    }
+    // largest first inside a class: the long-running workgroups start first
+    for (auto &v : out.desc)
+        std::stable_sort(v.begin(), v.end(), [](const SetDesc &a, const SetDesc &b) { return a.nnz + a.n_t > b.nnz + b.n_t; });
+    out.n_closed_tids = (int64_t)T - out.n_resident_tids - out.n_streamed_tids;
+    return 0;
+}
+
+// reference check of a packed record against the CSR it came from: every weighted multi-transcript row of a
+// resident component must be found (with its multiplicities) and the weights must add up.  Returns 0 if consistent.
+inline int check_sets(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx, const int32_t *wgt,
+                      const ResidentSets &S) {
+    const size_t T = (size_t)n_tx;
+    if (S.kind.size() != T || S.usum.size() != T) return 1;
+    std::vector<int32_t> set_of(T, -1), loc(T, -1);
+    std::vector<const SetDesc *> all;
+    for (const auto &v : S.desc) for (const auto &d : v) all.push_back(&d);
+    for (size_t s = 0; s < all.size(); s++) {
+        const SetDesc &d = *all[s];
+        if (d.n_t < 2 || d.n_r < 1) return 2;
+        if (S.rp[d.rp_off] != 0 || S.rp[d.rp_off + d.n_r] != d.nnz || S.cp[d.cp_off] != 0 || S.cp[d.cp_off + d.n_t] != d.nnz) return 3;
+        for (uint32_t i = 0; i < d.n_t; i++) {
+            int32_t t = S.g_tid[d.tid_off + i];
+            if (t < 0 || t >= n_tx || set_of[(size_t)t] >= 0 || S.kind[(size_t)t] != KIND_RESIDENT) return 4;
+            if (i && t <= S.g_tid[d.tid_off + i - 1]) return 4;
+            set_of[(size_t)t] = (int32_t)s; loc[(size_t)t] = (int32_t)i;
+            if (S.g_u[d.tid_off + i] != S.usum[(size_t)t]) return 5;
+        }
+        // CSC is the transpose of CSR
+        std::vector<uint32_t> seen(d.n_t, 0);
+        for (uint32_t j = 0; j < d.n_r; j++) {
+            if (S.rp[d.rp_off + j] > S.rp[d.rp_off + j + 1]) return 6;
+            for (uint32_t k = S.rp[d.rp_off + j]; k < S.rp[d.rp_off + j + 1]; k++) {
+                uint32_t i = S.ent[d.ent_off + k];
+                if (i >= d.n_t) return 6;
+                uint32_t q = S.cp[d.cp_off + i] + seen[i]++;
+                if (q >= S.cp[d.cp_off + i + 1] || S.crow[d.ent_off + q] != j) return 7;
+            }
+        }
+        for (uint32_t i = 0; i < d.n_t; i++) if (seen[i] != (uint32_t)(S.cp[d.cp_off + i + 1] - S.cp[d.cp_off + i])) return 7;
+    }
+    for (size_t t = 0; t < T; t++) if ((S.kind[t] == KIND_RESIDENT) != (set_of[t] >= 0)) return 8;
+    // every weighted row: single -> usum; multi -> all tids of one kind; resident rows are present in their set
+    std::vector<double> usum(T, 0.0), wsum(all.size(), 0.0), wfound(all.size(), 0.0);
+    std::vector<uint16_t> key;
+    for (int64_t r = 0; r < n_rows; r++) {
+        const int32_t x = wgt ? wgt[r] : 1;
+        const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+        if (x <= 0 || b == e) continue;
+        bool single = true;
+        for (uint64_t k = b + 1; k < e; k++) if (col_idx[k] != col_idx[b]) single = false;
+        if (single) { usum[(size_t)col_idx[b]] += x; continue; }
+        const uint8_t kd = S.kind[(size_t)col_idx[b]];
+        if (kd == KIND_CLOSED) return 9;
+        for (uint64_t k = b; k < e; k++) if (S.kind[(size_t)col_idx[k]] != kd) return 10;
+        if (kd != KIND_RESIDENT) continue;
+        const int32_t s = set_of[(size_t)col_idx[b]];
+        key.clear();
+        for (uint64_t k = b; k < e; k++) { if (set_of[(size_t)col_idx[k]] != s) return 11; key.push_back((uint16_t)loc[(size_t)col_idx[k]]); }
+        std::sort(key.begin(), key.end());
+        const SetDesc &d = *all[(size_t)s];
+        bool found = false;
+        for (uint32_t j = 0; j < d.n_r && !found; j++) {
+            const uint32_t a = S.rp[d.rp_off + j], len = S.rp[d.rp_off + j + 1] - a;
+            if (len == key.size() && std::equal(key.begin(), key.end(), S.ent.begin() + d.ent_off + a)) found = true;
+        }
+        if (!found) return 12;
+        wsum[(size_t)s] += x;
+    }
+    for (size_t t = 0; t < T; t++) if (usum[t] != S.usum[t]) return 13;
+    for (size_t s = 0; s < all.size(); s++) {
+        const SetDesc &d = *all[s];
+        for (uint32_t j = 0; j < d.n_r; j++) wfound[s] += S.row_w[d.row_off + j];
+        if (wfound[s] != wsum[s]) return 14;
+    }
+    return 0;
+}
+
+}  // namespace emsar
+#endif

@@ -18,7 +18,7 @@ SYMBOLS = [
     "emsar_hip_upload_structure", "emsar_hip_upload_sample", "emsar_hip_solve",
     "emsar_hip_reset_theta", "emsar_hip_set_theta", "emsar_hip_get_theta", "emsar_hip_run_passes",
     "emsar_hip_ieuma", "emsar_hip_normalise", "emsar_hip_get_info", "emsar_hip_layout_selfcheck",
-    "emsar_hip_layout_selfcheck_tiled",
+    "emsar_hip_layout_selfcheck_tiled", "emsar_hip_sets_selfcheck",
 ]
 
 
@@ -30,13 +30,22 @@ class EmsarHipError(RuntimeError):
 
 class EmParams(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("accel", C.c_int32), ("tol", C.c_double), ("abs_floor", C.c_double),
-                ("check_every", C.c_int32), ("reserved", C.c_int32), ("count_floor", C.c_double)]
+                ("check_every", C.c_int32), ("set_mode", C.c_int32), ("count_floor", C.c_double)]
 
 
 class EmStats(C.Structure):
     _fields_ = [("iters", C.c_int32), ("converged", C.c_int32), ("final_delta", C.c_double), ("loglik", C.c_double),
                 ("solve_ms", C.c_double), ("kernel_ms", C.c_double), ("bytes_per_pass", C.c_int64),
-                ("stored_bytes_per_pass", C.c_int64)]
+                ("stored_bytes_per_pass", C.c_int64),
+                ("sets_resident", C.c_int32), ("sets_streamed", C.c_int32), ("set_passes_max", C.c_int32),
+                ("sets_unconverged", C.c_int32), ("set_passes_sum", C.c_int64), ("sets_build_ms", C.c_double),
+                ("sets_kernel_ms", C.c_double)]
+
+
+class SetsInfo(C.Structure):
+    _fields_ = [("n_components", C.c_int64), ("sets_resident", C.c_int64 * 3), ("max_lds_bytes", C.c_int64 * 3),
+                ("sets_streamed", C.c_int64), ("tids_closed", C.c_int64), ("tids_resident", C.c_int64),
+                ("tids_streamed", C.c_int64), ("rows_in", C.c_int64), ("rows_stored", C.c_int64)]
 
 
 class Info(C.Structure):
@@ -77,6 +86,7 @@ def load_library():
     L.emsar_hip_get_info.argtypes = [vp, C.POINTER(Info)]
     L.emsar_hip_layout_selfcheck.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int32, C.c_int64, C.POINTER(Info)]
     L.emsar_hip_layout_selfcheck_tiled.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int, C.POINTER(Info)]
+    L.emsar_hip_sets_selfcheck.argtypes = [C.c_int64, C.c_int32, u64p, i32p, i32p, C.POINTER(SetsInfo)]
     _lib = L
     return L
 
@@ -106,6 +116,22 @@ def layout_selfcheck(n_tx, row_ptr, col_idx, window=0, chunk_entries=0):
     if rc != 0:
         raise EmsarHipError(rc, "layout_selfcheck")
     return info.as_dict()
+
+
+def sets_selfcheck(n_tx, row_ptr, col_idx, row_weight=None):
+    """Host-only: find + pack the connected sets for the set-resident solver and check the records (no GPU needed)."""
+    L = load_library()
+    row_ptr, col_idx = _arr(row_ptr, np.uint64), _arr(col_idx, np.int32)
+    w = None if row_weight is None else _arr(row_weight, np.int32)
+    info = SetsInfo()
+    rc = L.emsar_hip_sets_selfcheck(len(row_ptr) - 1, n_tx, _p(row_ptr, C.c_uint64), _p(col_idx, C.c_int32),
+                                    None if w is None else _p(w, C.c_int32), C.byref(info))
+    if rc != 0:
+        raise EmsarHipError(rc, "sets_selfcheck")
+    d = {k: getattr(info, k) for k, _ in SetsInfo._fields_}
+    d["sets_resident"] = list(d["sets_resident"])
+    d["max_lds_bytes"] = list(d["max_lds_bytes"])
+    return d
 
 
 def layout_selfcheck_tiled(n_tx, row_ptr, col_idx, merge_rows=False):
@@ -170,8 +196,9 @@ class EmsarHip:
         self._chk(self._L.emsar_hip_upload_sample(self._h, _p(w, C.c_int32), _p(e, C.c_double), _p(d, C.c_double)),
                   "upload_sample")
 
-    def solve(self, max_iter=100000, accel=1, tol=1e-10, abs_floor=1e-6, check_every=8, count_floor=0.0):
-        p = EmParams(max_iter, accel, tol, abs_floor, check_every, 0, count_floor)
+    def solve(self, max_iter=100000, accel=1, tol=1e-10, abs_floor=1e-6, check_every=8, count_floor=0.0, set_mode=0):
+        """set_mode 0: connected sets that fit a CU's LDS are solved by one workgroup each; 1: streaming passes only."""
+        p = EmParams(max_iter, accel, tol, abs_floor, check_every, set_mode, count_floor)
         st = EmStats()
         out = np.zeros(self.n_tx)
         self._chk(self._L.emsar_hip_solve(self._h, C.byref(p), _p(out, C.c_double), C.byref(st)), "solve")

@@ -112,3 +112,26 @@ def collapse(row_ptr, col_idx):
     new_rp[1:] = np.cumsum([len(k) for k in order])
     new_col = np.fromiter((t for k in order for t in k), dtype=np.int32, count=int(new_rp[-1]))
     return new_rp, new_col, np.array(counts, dtype=np.int32)
+
+
+def family_matrix(sizes, rows_per_tid=3, seed=0, dup=0.3, singles=0.3):
+    """Block-diagonal incidence: one family of transcripts per entry of `sizes`; rows draw 1..4 tids (with repeats)
+    from one family; a share `dup` of the rows repeats an earlier row (identical tid multiset)."""
+    rng = np.random.default_rng(seed)
+    rp, ci, w = [0], [], []
+    base = 0
+    for n in sizes:
+        fam_rows = []
+        for _ in range(max(1, rows_per_tid * n)):
+            if fam_rows and rng.random() < dup:
+                row = fam_rows[rng.integers(len(fam_rows))]
+            elif rng.random() < singles:
+                row = [base + int(rng.integers(n))] * int(rng.integers(1, 3))
+            else:
+                row = list(base + rng.integers(0, n, size=int(rng.integers(2, 5))))
+            fam_rows.append(row)
+            ci.extend(int(x) for x in row)
+            rp.append(len(ci))
+            w.append(int(rng.integers(0, 40)))
+        base += n
+    return base, np.array(rp, dtype=np.uint64), np.array(ci, dtype=np.int32), np.array(w, dtype=np.int32)

@@ -63,7 +63,10 @@ typedef struct {
     double  tol;          /* stop when max_t |dtheta_t| / (theta_t + abs_floor) < tol; <=0 -> 1e-10 */
     double  abs_floor;    /* <=0 -> 1e-6, the %lf print quantum of the reference's .fpkm */
     int32_t check_every;  /* host looks at the device convergence word every this many cycles; <=0 -> 8 */
-    int32_t reserved;
+    int32_t set_mode;     /* 0 = split the problem into its connected sets (run_MLE_threads' unit of work, emsar_main.c:446-474):
+                             sets that fit a CU's LDS are solved by one workgroup each with no kernel launch per pass,
+                             one-transcript sets in closed form, only the rest by the streaming passes;
+                             1 = streaming passes over the whole matrix only */
     double  count_floor;  /* optional second floor, in READS: the floor of transcript t becomes max(abs_floor, count_floor/den_t).
                              Transcripts whose optimum is the boundary theta = 0 with zero gradient decay like 1/k; a floor of
                              e.g. 1e-3 inferred reads stops the solve once only such components still move.  0 = off. */
@@ -78,6 +81,14 @@ typedef struct {
     double  kernel_ms;        /* device time of all EM passes (HIP events on the context's stream) */
     int64_t bytes_per_pass;   /* algorithmic bytes of one pass, SURVEY.md 8d: 4 nnz + P (rows+1) + W rows + 32 T */
     int64_t stored_bytes_per_pass; /* bytes the chosen layout actually streams per pass */
+    /* set_mode 0 only (else 0): how the transcripts were split and what the LDS-resident sets cost */
+    int32_t sets_resident;    /* connected sets solved inside one workgroup's LDS */
+    int32_t sets_streamed;    /* connected sets too large for that, solved by the streaming passes */
+    int32_t set_passes_max;   /* EM passes of the slowest resident set (iters = streaming passes + this) */
+    int32_t sets_unconverged; /* resident sets that hit max_iter */
+    int64_t set_passes_sum;   /* EM passes summed over the resident sets */
+    double  sets_build_ms;    /* host time spent finding and packing the sets (once per upload_sample) */
+    double  sets_kernel_ms;   /* device time of the resident-set kernels */
 } emsar_em_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
@@ -148,6 +159,19 @@ int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row
 /* The same for the TILED layout (forward index, transposed index, dictionaries, folded and leftover rows). */
 int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                                      int merge_rows, emsar_hip_info *info_out);
+
+/* The same for the set-resident solver's records (set_mode 0): find the connected sets of the rows with weight > 0
+ * (row_weight NULL = every row counts 1), pack the ones that fit a workgroup's LDS and check the records against the CSR. */
+typedef struct {
+    int64_t n_components;        /* connected sets with at least two transcripts */
+    int64_t sets_resident[3];    /* by workgroup class: 64 / 256 / 512 threads */
+    int64_t max_lds_bytes[3];    /* largest LDS footprint in each class */
+    int64_t sets_streamed;       /* sets too large for one workgroup */
+    int64_t tids_closed, tids_resident, tids_streamed;
+    int64_t rows_in, rows_stored; /* weighted multi-transcript rows before / after merging identical ones */
+} emsar_hip_sets_info;
+int emsar_hip_sets_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
+                             const int32_t *row_weight, emsar_hip_sets_info *info_out);
 
 #ifdef __cplusplus
 }

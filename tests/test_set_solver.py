@@ -1,0 +1,106 @@
+"""GPU parity of the set-resident solver (emsar_em_params.set_mode 0): connected sets solved by one workgroup each out
+of LDS, one-transcript sets in closed form, oversized sets by the streaming passes -- against the streaming solve
+(set_mode 1) and the CPU oracle, on the golden fixtures and on block matrices that exercise every workgroup class.
+
+Tolerance: both solves stop at max_t |dtheta|/(theta+1e-6) < tol on a plain EM step; they follow different SQUAREM
+trajectories (per set vs global step length), so theta is compared at 1e-6 relative + 1.5e-6 absolute (the .fpkm print
+quantum) and F at 1e-10 relative."""
+import numpy as np
+import pytest
+
+import oracle as O
+from emsar_amd import EmsarHip
+from emsar_amd.hip import LAYOUT_CSR, LAYOUT_TILED
+from emsar_amd.synth import family_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    ctx = EmsarHip(0)
+    yield ctx
+    ctx.close()
+
+
+def close(a, b):
+    return np.all(np.abs(a - b) <= 1e-6 * np.abs(b) + 1.5e-6)
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+def test_fixtures_resident_vs_streaming_vs_reference(dev, golden, accel):
+    m = golden.model
+    dev.upload_structure(m.n_tx, m.row_ptr, m.col_idx, LAYOUT_TILED)
+    dev.upload_sample(m.R, m.E, None)
+    th_s, st_s = dev.solve(max_iter=600000, accel=accel, tol=1e-10, set_mode=1)
+    th_r, st_r = dev.solve(max_iter=600000, accel=accel, tol=1e-10, set_mode=0)
+    assert st_r.converged == 1 and st_r.sets_unconverged == 0 and st_r.sets_streamed == 0
+    assert st_s.sets_resident == 0 and st_s.set_passes_max == 0
+    golden.check_fpkm_parity(th_r, "set-resident accel=%d" % accel)
+    assert close(th_r, th_s)
+    F = m.loglik(th_r)
+    assert abs(st_r.loglik - F) <= 1e-9 * abs(F)
+    assert st_r.loglik >= st_s.loglik - 1e-10 * abs(F)
+    assert st_r.iters == st_r.set_passes_max
+    # no atomics anywhere on the resident path: a second solve is identical to the last bit
+    th_r2, st_r2 = dev.solve(max_iter=600000, accel=accel, tol=1e-10, set_mode=0)
+    np.testing.assert_array_equal(th_r, th_r2)
+    assert st_r2.set_passes_sum == st_r.set_passes_sum
+
+
+@pytest.mark.parametrize("layout", [LAYOUT_CSR, LAYOUT_TILED])
+def test_every_class_and_a_streamed_set(dev, layout):
+    n_tx, rp, ci, w = family_matrix([2, 3, 5, 8, 40, 200, 900, 2500, 6000] + [4] * 300, rows_per_tid=2, seed=5)
+    rng = np.random.default_rng(9)
+    E = rng.uniform(0.5, 2.0, size=len(w))
+    E[rng.random(len(w)) < 0.05] = 0.0                    # rows outside the likelihood
+    dev.upload_structure(n_tx, rp, ci, layout)
+    dev.upload_sample(w, E, None)
+    th_r, st_r = dev.solve(max_iter=400000, accel=1, tol=1e-10, set_mode=0)
+    th_s, st_s = dev.solve(max_iter=400000, accel=1, tol=1e-10, set_mode=1)
+    assert st_r.converged == 1 and st_s.converged == 1
+    assert st_r.sets_streamed >= 1 and st_r.sets_resident >= 300
+    m = O.Csr(n_tx, rp, ci, R=w, E=E)
+    th_o, st_o = m.em_solve(max_iter=400000, accel=1, tol=1e-10, n_threads=4)
+    F_o = m.loglik(th_o)
+    assert abs(st_r.loglik - F_o) <= 1e-10 * abs(F_o) and abs(st_s.loglik - F_o) <= 1e-10 * abs(F_o)
+    assert abs(m.loglik(th_r) - st_r.loglik) <= 1e-10 * abs(F_o)
+    # random families hold transcripts that only ever occur together: the likelihood is flat along such directions and
+    # each trajectory ends somewhere else on the same face.  What the MLE does pin down are the fitted segment rates
+    # S_c = sum_t m_ct theta_t of the rows inside the likelihood (F is strictly concave in them).
+    inside = (E > 0) & (w > 0)
+    S = lambda th: np.add.reduceat(th[ci], rp[:-1].astype(np.int64))[inside]
+    S_o, S_r, S_s = S(th_o), S(th_r), S(th_s)
+    assert np.all(np.abs(S_r - S_o) <= 1e-5 * S_o + 1.5e-6)
+    assert np.all(np.abs(S_r - S_s) <= 1e-5 * S_s + 1.5e-6)
+    den = m.den()
+    assert abs((th_r * den).sum() - (th_o * den).sum()) <= 1e-8 * (th_o * den).sum()      # total inferred reads
+
+
+def test_closed_form_and_unweighted(dev):
+    # every row has one transcript: theta = reads / den exactly, zero passes on any set
+    rp = np.array([0, 1, 3, 4, 4], dtype=np.uint64)
+    ci = np.array([0, 1, 1, 2], dtype=np.int32)
+    R = np.array([4, 6, 0, 3], dtype=np.int32)
+    E = np.array([2.0, 1.5, 4.0, 1.0])
+    dev.upload_structure(4, rp, ci, LAYOUT_TILED)
+    dev.upload_sample(R, E, None)
+    th, st = dev.solve(set_mode=0)
+    np.testing.assert_allclose(th, [2.0, 2.0, 0.0, 0.0], rtol=1e-15)       # den = [2, 3, 4, 0]
+    assert st.converged == 1 and st.iters == 0 and st.sets_resident == 0
+    # read-level rows without weights, two families
+    n_tx, rp, ci, _ = family_matrix([6, 9], rows_per_tid=20, seed=2)
+    dev.upload_structure(n_tx, rp, ci, LAYOUT_TILED)
+    dev.upload_sample(None, None, None)
+    a, st_a = dev.solve(tol=1e-11, set_mode=0)
+    b, st_b = dev.solve(tol=1e-11, set_mode=1)
+    assert st_a.sets_resident == 2 and close(a, b)
+
+
+def test_max_iter_is_reported(dev, golden):
+    m = golden.model
+    dev.upload_structure(m.n_tx, m.row_ptr, m.col_idx, LAYOUT_TILED)
+    dev.upload_sample(m.R, m.E, None)
+    th, st = dev.solve(max_iter=4, accel=1, tol=1e-14, set_mode=0)
+    if st.sets_resident:
+        assert st.set_passes_max <= 6 and (st.converged == 0) == (st.sets_unconverged > 0)

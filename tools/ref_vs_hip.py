@@ -46,6 +46,8 @@ with tempfile.TemporaryDirectory() as d:
     import json
     st = json.load(open(os.path.join(d, "st.json")))["per_sample"][0]
     print("emsar-hip breakdown: parse %.2f s, solve %.3f s (%d EM passes, converged %d)" % (st["parse_s"], st["solve_ms"] / 1e3, st["em_passes"], st["converged"]))
+    print("  sets: %d resident (slowest %d passes, %d summed, kernel %.2f ms, host packing %.2f ms), %d streamed"
+          % (st["sets_resident"], st["set_passes_max"], st["set_passes_sum"], st["sets_kernel_ms"], st["sets_build_ms"], st["sets_streamed"]))
     a = O.read_fpkm(os.path.join(d, "r1", "o.0.fpkm"))["fpkm"]
     b = O.read_fpkm(os.path.join(d, "rp", "o.0.fpkm"))["fpkm"]
     h = O.read_fpkm(os.path.join(d, "h", "o.0.fpkm"))["fpkm"]
