@@ -56,3 +56,10 @@ with tempfile.TemporaryDirectory() as d:
     print("reference -p1 vs -p%d : %d transcripts differ beyond 1e-5 rel + 1.5e-6 (its own noise)" % (threads, int((np.abs(a - b) > tol(a)).sum())))
     print("emsar-hip vs reference: %d transcripts differ beyond 1e-5 rel + 1.5e-6; max rel diff on FPKM > 1: %.2e"
           % (int((np.abs(h - a) > tol(a)).sum()), float((np.abs(h - a) / np.maximum(a, 1e-300))[a > 1].max())))
+    # the reference's two runs disagree where the likelihood is flat (its answer there depends on the
+    # thread schedule); off that mask the comparison is meaningful
+    quiet = np.abs(a - b) <= tol(a)
+    bad = quiet & (np.abs(h - a) > tol(a))
+    print("off the reference's own noise mask (%d transcripts): %d differ; max rel diff on FPKM > 1: %.2e"
+          % (int(quiet.sum()), int(bad.sum()), float((np.abs(h - a) / np.maximum(a, 1e-300))[quiet & (a > 1)].max())))
+    seg = lambda p: O.read_segments(p, n_tx) if os.path.exists(p) else None
