@@ -272,7 +272,7 @@ __global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restri
 // k_pass_tiled: one EM pass over the TILED layout (layout_tiled.hpp).  One workgroup = 4 waves = the 4 slices of a tile.
 //   phase 0  every global load the wave needs first is issued at once (dictionary theta values, 8 forward columns,
 //            8 backward segments); dictionary: th_w[d] = theta[tid(d)], acc_w[d] = 0, zero slots; barrier
-//   phase E  the wave owns one slice (768 rows, lane = 12 rows): S_r = sum th_w[id]  (LDS reads only, 10-bit ids,
+//   phase E  the wave owns one slice (768 rows; lane l holds rows 64*i + l, i < 12): S_r = sum th_w[id]  (LDS reads only, 10-bit ids,
 //            padding reads the zero slot: no branches), w_r = R_r / S_r -> the wave's own 6 KiB of LDS
 //   phase M  the SAME wave walks the transposed index of its rows: a lane's segments (column id + 11 row ids) are
 //            consecutive in column order; it gathers w_r from LDS into a register sum and adds it to acc_w when the
@@ -299,37 +299,64 @@ __device__ __forceinline__ void load8_clamped(int4 (&q)[8], const int4 *e, int n
     for (int j = 0; j < 8; j++) q[j] = e[(size_t)(j < n ? j : n - 1) * 64];
 }
 
+// LDS gather of the double named by 10-bit field F of a packed dword: two VALU instructions per entry
+// (v_bfe_u32 + v_lshl_add_u32 with the region's LDS byte address as the scalar addend) instead of the shift / and /
+// add-base triple hipcc emits for the C expression -- the E- and M-steps are bound by instruction issue
+// (4 cycles per wave64 instruction on a 16-lane SIMD), not by LDS bandwidth.
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+__device__ __forceinline__ unsigned lds_byte_addr(const void *p) { return (unsigned)(uintptr_t)p; }   // low half of a flat LDS address
+template <int F>
+__device__ __forceinline__ unsigned lds_id_addr(unsigned dword, unsigned base /* wave-uniform */) {
+    // inline asm: hipcc rewrites the C expression (and the ubfe intrinsic) back into shift + and + add
+    unsigned a;   // one statement: hipcc pads a nop between two dependent asm statements
+    asm("v_bfe_u32 %0, %1, %2, 10\n\tv_lshl_add_u32 %0, %0, 3, %3" : "=v"(a) : "v"(dword), "i"(10 * F), "s"(base));
+    return a;
+}
+__device__ __forceinline__ double lds_ld(unsigned a) { return *reinterpret_cast<lds_cdouble *>(a); }
+// the LDS byte addresses of the 12 ids of one int4 (addresses first, then the loads back to back, then the adds: the
+// asm statements would otherwise serialise address -> load -> wait -> add per entry)
+__device__ __forceinline__ void lds_addr12(const int4 t, unsigned base, unsigned (&a)[12]) {
+    const unsigned d0 = (unsigned)t.x, d1 = (unsigned)t.y, d2 = (unsigned)t.z, d3 = (unsigned)t.w;
+    a[0] = lds_id_addr<0>(d0, base); a[1] = lds_id_addr<1>(d0, base); a[2] = lds_id_addr<2>(d0, base);
+    a[3] = lds_id_addr<0>(d1, base); a[4] = lds_id_addr<1>(d1, base); a[5] = lds_id_addr<2>(d1, base);
+    a[6] = lds_id_addr<0>(d2, base); a[7] = lds_id_addr<1>(d2, base); a[8] = lds_id_addr<2>(d2, base);
+    a[9] = lds_id_addr<0>(d3, base); a[10] = lds_id_addr<1>(d3, base); a[11] = lds_id_addr<2>(d3, base);
+}
+
 // E-step sums of up to 8 forward columns held in registers (n is wave-uniform); one int4 = this lane's 12 rows
-__device__ __forceinline__ void fwd_sum_regs(const int4 (&q)[8], int n, const double *th_w, double (&S)[kRPL]) {
+__device__ __forceinline__ void fwd_sum_regs(const int4 (&q)[8], int n, unsigned th_base, double (&S)[kRPL]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         if (j < n) {
-            const int4 t = q[j];
-            const unsigned d[4] = {(unsigned)t.x, (unsigned)t.y, (unsigned)t.z, (unsigned)t.w};
+            unsigned a[12];
+            double v[12];
+            lds_addr12(q[j], th_base, a);
 #pragma unroll
-            for (int i = 0; i < kRPL; i++) S[i] += lds_at(th_w, id_off(d[i / 3], i % 3));
+            for (int i = 0; i < 12; i++) v[i] = lds_ld(a[i]);
+#pragma unroll
+            for (int i = 0; i < 12; i++) S[i] += v[i];
         }
     }
 }
 
 // M-step of up to 8 backward segments of one lane ({column, 11 row ids} each).  A lane's segments are consecutive
 // in column order: the running sum stays in a register and goes to the LDS accumulator when the column changes.
-__device__ __forceinline__ void bwd_sum_regs(const int4 (&q)[8], int n, const double *w_s, double *acc_w, unsigned &cur, double &part) {
+__device__ __forceinline__ void bwd_sum_regs(const int4 (&q)[8], int n, unsigned ws_base, double *acc_w, unsigned &cur, double &part) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         if (j < n) {
-            const int4 t = q[j];
-            const unsigned d[4] = {(unsigned)t.x, (unsigned)t.y, (unsigned)t.z, (unsigned)t.w};
-            const unsigned col = id_off(d[0], 0);
+            unsigned a[12];
+            double v[12];
+            lds_addr12(q[j], ws_base, a);
+#pragma unroll
+            for (int i = 1; i < 12; i++) v[i] = lds_ld(a[i]);
+            const unsigned col = id_off((unsigned)q[j].x, 0);
             if (col != cur) {
                 if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
                 cur = col; part = 0.0;
             }
-            double s0 = lds_at(w_s, id_off(d[0], 1)) + lds_at(w_s, id_off(d[0], 2));
-            double s1 = lds_at(w_s, id_off(d[1], 0)) + lds_at(w_s, id_off(d[1], 1));
-            double s2 = lds_at(w_s, id_off(d[1], 2)) + lds_at(w_s, id_off(d[2], 0));
-            double s3 = lds_at(w_s, id_off(d[2], 1)) + lds_at(w_s, id_off(d[2], 2));
-            s0 += lds_at(w_s, id_off(d[3], 0)); s1 += lds_at(w_s, id_off(d[3], 1)); s2 += lds_at(w_s, id_off(d[3], 2));
+            double s0 = v[1] + v[2], s1 = v[3] + v[4], s2 = v[5] + v[6], s3 = v[7] + v[8];
+            s0 += v[9]; s1 += v[10]; s2 += v[11];
             part += (s0 + s1) + (s2 + s3);
         }
     }
@@ -364,6 +391,8 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool has_slice = wave < (int)T.n_slices;
     double *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;     // this wave's row weights [768] + zero row
+    const unsigned th_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(th_w));
+    const unsigned ws_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(w_s));
 
     // ---- issue every global load this wave needs first, in the order of use: dictionary values, 8 forward columns,
     //      8 backward segments.  One HBM round trip per tile; the rest of the pass touches LDS only.
@@ -412,12 +441,12 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     double ll = 0.0;
     if (has_slice) {
         // ---- E: row sums of this wave's 768 rows ----
-        const size_t slot0 = (size_t)T.row_base + (size_t)wave * emsar::kTileSliceRows + kRPL * lane;
+        // row i of lane l is slot 64*i + l of the slice: the lanes of one gather hold consecutive sorted rows
+        const size_t slot0 = (size_t)T.row_base + (size_t)wave * emsar::kTileSliceRows + lane;
         double w[kRPL];
         if (MODE == MODE_SCATTER) {
-            const double2 *rv = reinterpret_cast<const double2 *>(rowval + slot0);
 #pragma unroll
-            for (int i = 0; i < kRPL / 2; i++) { double2 v = rv[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
+            for (int i = 0; i < kRPL; i++) w[i] = rowval[slot0 + 64 * i];
         } else {
             double S[kRPL];
 #pragma unroll
@@ -425,15 +454,14 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
             for (int j0 = 0; j0 < k; j0 += 8) {
                 const int n0 = k - j0 < 8 ? k - j0 : 8;
                 if (j0) load8_clamped(A, e + (size_t)j0 * 64, n0);
-                fwd_sum_regs(A, n0, th_w, S);
+                fwd_sum_regs(A, n0, th_base, S);
             }
             double r[kRPL];
 #pragma unroll
             for (int i = 0; i < kRPL; i++) r[i] = 1.0;
             if (WEIGHTED) {
-                const int4 *rw = reinterpret_cast<const int4 *>(wgt + slot0);
 #pragma unroll
-                for (int i = 0; i < kRPL / 4; i++) { int4 x = rw[i]; r[4 * i] = x.x; r[4 * i + 1] = x.y; r[4 * i + 2] = x.z; r[4 * i + 3] = x.w; }
+                for (int i = 0; i < kRPL; i++) r[i] = (double)wgt[slot0 + 64 * i];
             }
 #pragma unroll
             for (int i = 0; i < kRPL; i++) {
@@ -442,9 +470,8 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
                 if (MODE == MODE_EM_LL && live) ll += r[i] * log(S[i]);
             }
         }
-        double2 *dst = reinterpret_cast<double2 *>(w_s + kRPL * lane);
 #pragma unroll
-        for (int i = 0; i < kRPL / 2; i++) dst[i] = make_double2(w[2 * i], w[2 * i + 1]);
+        for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = w[i];
         // the M-step below reads rows written by OTHER lanes of this same wave: DS operations of one wave execute in
         // order, so only the compiler has to be kept from moving the reads up
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -457,7 +484,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
         for (int j0 = 0; j0 < m; j0 += 8) {
             const int n0 = m - j0 < 8 ? m - j0 : 8;
             if (j0) load8_clamped(B, b + (size_t)j0 * 64, n0);
-            bwd_sum_regs(B, n0, w_s, acc_w, cur, part);
+            bwd_sum_regs(B, n0, ws_base, acc_w, cur, part);
         }
         if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
         for (unsigned q = lane; q < coo_n; q += 64) {
@@ -480,6 +507,172 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     }
     if (STAMP && lane == 0) {   // [tile][wave][5 phases]: issue+dictionary, barrier, E, M, barrier
         for (int i = 0; i < 5; i++) stamps[((size_t)blockIdx.x * (kTiledThreads / 64) + wave) * 8 + i] = ts[i + 1] - ts[i];
+    }
+    if (MODE == MODE_EM_LL) {
+        double t = block_sum<kTiledThreads>(ll, red);
+        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pass_tiled_pair: the same pass, two tiles per workgroup, software-pipelined by hand.  In k_pass_tiled a wave has
+// loads in flight only at its start (~20 % of its life); with four workgroups per CU there is often nobody loading and
+// the CU's share of HBM idles.  Here the forward registers are refilled with tile 1's columns as soon as tile 0's E-step
+// has consumed them, the backward registers after tile 0's M-step, and tile 1's dictionary values are requested before
+// tile 0's M-step: tile 1's HBM round trip hides behind tile 0's LDS work.
+// ------------------------------------------------------------------------------------------------
+struct TileWave {           // what one wave needs to know about its slice of a tile (all wave-uniform but e/b)
+    const int4 *e, *b;
+    int k, m, nd;
+    unsigned coo_base, coo_n;
+    bool has_slice;
+};
+__device__ __forceinline__ TileWave tile_wave(const Tile &T, int wave, int lane, const uint32_t *fwd, const uint32_t *bwd) {
+    TileWave W;
+    W.nd = (int)T.near_n + (int)T.far_n;
+    W.has_slice = wave < (int)T.n_slices;
+    W.e = nullptr; W.b = nullptr; W.k = 0; W.m = 0; W.coo_base = T.coo_off; W.coo_n = 0;
+    if (W.has_slice) {
+        unsigned foff = 0, boff = 0;
+        int k = 0, m = 0; unsigned cn = 0, cb = T.coo_off;
+#pragma unroll
+        for (int s = 0; s < emsar::kTileSlices; s++) {
+            if (s < wave) { foff += T.k[s]; boff += T.m[s]; cb += T.coo_n[s]; }
+            if (s == wave) { k = T.k[s]; m = T.m[s]; cn = T.coo_n[s]; }
+        }
+        W.k = __builtin_amdgcn_readfirstlane(k); W.m = __builtin_amdgcn_readfirstlane(m);
+        W.coo_n = __builtin_amdgcn_readfirstlane(cn); W.coo_base = __builtin_amdgcn_readfirstlane(cb);
+        foff = __builtin_amdgcn_readfirstlane(foff); boff = __builtin_amdgcn_readfirstlane(boff);
+        W.e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 4 + (size_t)foff * 256) + lane;
+        W.b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 4 + (size_t)boff * 256) + lane;
+    }
+    return W;
+}
+__device__ __forceinline__ void tile_dict_issue(const Tile &T, int nd, const int32_t *far_tid, const double *theta, double (&thv)[4], int (&tid_d)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int d = threadIdx.x + i * kTiledThreads;
+        thv[i] = 0.0; tid_d[i] = -1;
+        if (d < nd) {
+            tid_d[i] = d < (int)T.near_n ? T.lo + d : far_tid[T.far_off + (d - (int)T.near_n)];
+            thv[i] = theta[tid_d[i]];
+        }
+    }
+}
+__device__ __forceinline__ void tile_dict_store(int nd, const double (&thv)[4], double *th_w, double *acc_w) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int d = threadIdx.x + i * kTiledThreads;
+        if (d <= nd) { th_w[d] = thv[i]; acc_w[d] = 0.0; }
+    }
+}
+template <bool WEIGHTED, int MODE>
+__device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], size_t slot0, const int32_t *wgt, const double *th_w, double *w_s,
+                                            int lane, double &ll) {
+    const unsigned th_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(th_w));
+    double S[kRPL], w[kRPL], r[kRPL];
+#pragma unroll
+    for (int i = 0; i < kRPL; i++) { S[i] = 0.0; r[i] = 1.0; }
+    for (int j0 = 0; j0 < W.k; j0 += 8) {
+        const int n0 = W.k - j0 < 8 ? W.k - j0 : 8;
+        if (j0) load8_clamped(A, W.e + (size_t)j0 * 64, n0);
+        fwd_sum_regs(A, n0, th_base, S);
+    }
+    if (WEIGHTED) {
+#pragma unroll
+        for (int i = 0; i < kRPL; i++) r[i] = (double)wgt[slot0 + 64 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < kRPL; i++) {
+        bool live = (S[i] > 0.0) && (r[i] > 0.0);
+        w[i] = live ? r[i] / S[i] : 0.0;
+        if (MODE == MODE_EM_LL && live) ll += r[i] * log(S[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = w[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], const uint32_t *coo, const double *w_s, double *acc_w, int lane) {
+    const unsigned ws_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(w_s));
+    unsigned cur = 0xFFFFFFFFu;
+    double part = 0.0;
+    for (int j0 = 0; j0 < W.m; j0 += 8) {
+        const int n0 = W.m - j0 < 8 ? W.m - j0 : 8;
+        if (j0) load8_clamped(B, W.b + (size_t)j0 * 64, n0);
+        bwd_sum_regs(B, n0, ws_base, acc_w, cur, part);
+    }
+    if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
+    for (unsigned q = lane; q < W.coo_n; q += 64) {
+        const unsigned p = coo[W.coo_base + q];
+        const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
+        if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + ((p >> 16) << 3)), v);
+    }
+}
+__device__ __forceinline__ void tile_flush(int nd, const int (&tid_d)[4], const double *acc_w, double *acc) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int d = threadIdx.x + i * kTiledThreads;
+        if (d < nd) {
+            const double v = acc_w[d];
+            if (v != 0.0) atomic_add_f64(&acc[tid_d[i]], v);
+        }
+    }
+}
+
+template <bool WEIGHTED, int MODE>
+__global__ __launch_bounds__(kTiledThreads, 3) void k_pass_tiled_pair(const Tile *__restrict__ tiles, int n_tiles, const uint32_t *__restrict__ fwd,
+                                                                   const uint32_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
+                                                                   const int32_t *__restrict__ far_tid, const int32_t *__restrict__ wgt,
+                                                                   const double *__restrict__ theta, double *__restrict__ acc,
+                                                                   double *__restrict__ ll_out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *th_w = lds, *acc_w = lds + kTiledDictPad;
+    __shared__ double red[kTiledThreads / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;
+    const int i0 = blockIdx.x, i1 = blockIdx.x + gridDim.x;
+    const bool has1 = i1 < n_tiles;
+    const Tile T0 = tiles[i0];
+    const Tile T1 = tiles[has1 ? i1 : i0];
+    const TileWave W0 = tile_wave(T0, wave, lane, fwd, bwd);
+
+    double thv[4]; int tid0[4], tid1[4];
+    int4 A[8], B[8];
+    tile_dict_issue(T0, W0.nd, far_tid, theta, thv, tid0);
+    if (W0.has_slice) {
+        load8_clamped(A, W0.e, W0.k < 8 ? W0.k : 8);
+        if (W0.m > 0) load8_clamped(B, W0.b, W0.m < 8 ? W0.m : 8);
+    }
+    tile_dict_store(W0.nd, thv, th_w, acc_w);
+    if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;
+    __syncthreads();
+    double ll = 0.0;
+    if (W0.has_slice)
+        tile_e_step<WEIGHTED, MODE>(W0, A, (size_t)T0.row_base + (size_t)wave * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
+    // tile 1: forward columns into the registers the E-step has just released, dictionary values requested now
+    const TileWave W1 = tile_wave(T1, wave, lane, fwd, bwd);
+    if (has1) {
+        if (W1.has_slice) load8_clamped(A, W1.e, W1.k < 8 ? W1.k : 8);
+        tile_dict_issue(T1, W1.nd, far_tid, theta, thv, tid1);
+    }
+    if (W0.has_slice) tile_m_step(W0, B, coo, w_s, acc_w, lane);
+    if (has1 && W1.has_slice && W1.m > 0) load8_clamped(B, W1.b, W1.m < 8 ? W1.m : 8);
+    __syncthreads();
+    tile_flush(W0.nd, tid0, acc_w, acc);
+    if (has1) {
+        // a thread rewrites only the dictionary slots it has just flushed; the barrier orders the new dictionary
+        // before the other waves' reads
+        tile_dict_store(W1.nd, thv, th_w, acc_w);
+        __syncthreads();
+        if (W1.has_slice) {
+            tile_e_step<WEIGHTED, MODE>(W1, A, (size_t)T1.row_base + (size_t)wave * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
+            tile_m_step(W1, B, coo, w_s, acc_w, lane);
+        }
+        __syncthreads();
+        tile_flush(W1.nd, tid1, acc_w, acc);
     }
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);
@@ -907,6 +1100,7 @@ struct emsar_hip_ctx {
     int64_t bytes_formula = 0, bytes_stored = 0;
     int64_t tl_fwd_slots = 0, tl_n_fslices = 0;
     double count_floor = 0.0;    // stopping-rule floor in reads for the current solve (emsar_em_params.count_floor)
+    bool tiled_pair = false;     // two tiles per workgroup (k_pass_tiled_pair)
     const uint8_t *delta_mask = nullptr;   // d_kind while the streaming solve runs next to resident sets
     // set-resident solver (sets.hpp): host copy of the CSR and of the sample's row weights, built lazily by solve
     std::vector<uint64_t> h_row_ptr;
@@ -981,9 +1175,17 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
 #define LAUNCH_T(WT, MD)                                                                                          \
     hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, ctx->d_tiles, ctx->d_fwd, ctx->d_bwd,   \
                        ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out)
+#define LAUNCH_P(WT, MD)                                                                                          \
+    hipLaunchKernelGGL((k_pass_tiled_pair<WT, MD>), dim3((unsigned)((ctx->n_tiles + 1) / 2)), block, lds, ctx->stream, ctx->d_tiles,  \
+                       (int)ctx->n_tiles, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, theta, acc, ll_out)
             if (mode == MODE_SCATTER) LAUNCH_T(false, MODE_SCATTER);
+            else if (ctx->tiled_pair) {
+                if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_P(true, MODE_EM_LL); else LAUNCH_P(true, MODE_EM); }
+                else { if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM); }
+            }
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
             else { if (mode == MODE_EM_LL) LAUNCH_T(false, MODE_EM_LL); else LAUNCH_T(false, MODE_EM); }
+#undef LAUNCH_P
 #undef LAUNCH_T
         }
         if (ctx->n_left > 0) {   // rows too long for a tile: generic CSR kernel on the leftover
@@ -1251,6 +1453,10 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
 #define SETLDS_T(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             SETLDS_T(false, MODE_EM); SETLDS_T(false, MODE_EM_LL); SETLDS_T(true, MODE_EM); SETLDS_T(true, MODE_EM_LL); SETLDS_T(false, MODE_SCATTER);
 #undef SETLDS_T
+#define SETLDS_P(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_pair<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+            SETLDS_P(false, MODE_EM); SETLDS_P(false, MODE_EM_LL); SETLDS_P(true, MODE_EM); SETLDS_P(true, MODE_EM_LL);
+#undef SETLDS_P
+            { const char *pe = getenv("EMSAR_HIP_TILED_PAIR"); ctx->tiled_pair = pe && atoi(pe) != 0; }
         } else if (layout == EMSAR_LAYOUT_WINDOWED) {
             const char *wenv = getenv("EMSAR_HIP_WINDOW");
             int window = wenv ? atoi(wenv) : kDefaultWindow;

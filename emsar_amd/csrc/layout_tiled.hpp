@@ -49,7 +49,7 @@ constexpr int64_t kTileEntries = 65536;
 struct Tile {                // 64 bytes
     uint64_t fwd_off;        // byte offset into fwd (multiple of 1024)
     uint64_t bwd_off;        // byte offset into bwd (multiple of 1024)
-    uint32_t row_base;       // first row slot of the tile (multiple of 768); slot = row_base + slice*768 + 12*lane + i
+    uint32_t row_base;       // first row slot of the tile (multiple of 768); slot = row_base + slice*768 + 64*i + lane
     uint32_t far_off;        // index of the tile's first far tid in far_tid[]
     uint32_t coo_off;        // index of the tile's first pair in coo[]
     int32_t lo;              // dictionary slot d < near_n  <->  tid lo + d
@@ -263,7 +263,9 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         T.coo_off = (uint32_t)out.coo.size();
         out.n_fslices += T.n_slices;
         // 3. forward slices (all of them first: the tile's forward block is contiguous).  Column j of a slice is 256
-        //    dwords; row i of the slice is field i%12 of the int4 of lane i/12
+        //    dwords; row p of the slice (p = position in sorted order) is field p/64 of the int4 of lane p%64: the 64
+        //    lanes of one E-step gather read 64 CONSECUTIVE sorted rows, i.e. mostly one family -- the same few
+        //    dictionary slots (LDS broadcast) or neighbouring ones (distinct banks) instead of a random spread
         uint32_t zero_dword = zero_id | (zero_id << 10) | (zero_id << 20);
         for (int s = 0; s < T.n_slices; s++) {
             int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
@@ -280,8 +282,9 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 uint64_t b = row_ptr[r], e = row_ptr[r + 1];
                 for (uint64_t q = b; q < e; q++) {
                     int32_t d = loc[(size_t)col_idx[q]];
-                    uint32_t *dw = &out.fwd[base + (size_t)(q - b) * kSliceDwords + in_slice / 3];
-                    const int sh = 10 * (int)(in_slice % 3);
+                    const uint32_t fl = in_slice & 63u, fi = in_slice >> 6;      // lane, field: see slot numbering above
+                    uint32_t *dw = &out.fwd[base + (size_t)(q - b) * kSliceDwords + fl * 4 + fi / 3];
+                    const int sh = 10 * (int)(fi % 3);
                     *dw = (*dw & ~(0x3FFu << sh)) | ((uint32_t)d << sh);
                     if (d >= near_n) out.far_entries++;
                 }
@@ -381,7 +384,8 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
                 int64_t r = L.slot_row[(size_t)T.row_base + (size_t)s * kTileSliceRows + (size_t)i];
                 a.clear();
                 for (int j = 0; j < T.k[s]; j++) {
-                    int d = (int)((L.fwd[foff + (size_t)j * kSliceDwords + (size_t)(i / 3)] >> (10 * (i % 3))) & 0x3FFu);
+                    const int fl = i & 63, fi = i >> 6;
+                    int d = (int)((L.fwd[foff + (size_t)j * kSliceDwords + (size_t)(fl * 4 + fi / 3)] >> (10 * (fi % 3))) & 0x3FFu);
                     if (d > nd) return -4;
                     if (d == nd) continue;                        // zero slot = padding
                     a.push_back(tid_of(d));
