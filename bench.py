@@ -108,6 +108,8 @@ def main():
     out = None
     if rank == 0:
         per_pass_s = kernel_ms / 1e3 / args.steps
+        # unweighted TILED passes run two tiles per workgroup unless EMSAR_HIP_TILED_MULTI=0 (emsar_hip.hip, launch_pass)
+        tiled_kernel = "k_pass_tiled" if os.environ.get("EMSAR_HIP_TILED_MULTI", "2") in ("0", "1") else "k_pass_tiled_multi<2>"
         bytes_pass = info["bytes_per_pass"]
         achieved = bytes_pass / per_pass_s / 1e9
         out = {
@@ -120,7 +122,7 @@ def main():
             "read_alignments_per_s": world * nnz * args.steps / wall,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": {1: "k_pass_csr", 2: "k_pass_windowed", 3: "k_pass_tiled", 259: "k_pass_tiled"}[info["layout"]] + "+k_update",
+                         "kernel": {1: "k_pass_csr", 2: "k_pass_windowed", 3: tiled_kernel, 259: "k_pass_tiled"}[info["layout"]] + "+k_update",
                          "algorithmic_bytes_per_pass": bytes_pass, "stored_bytes_per_pass": info["stored_bytes_per_pass"],
                          "device_ms_per_pass": per_pass_s * 1e3},
             "layout_stats": {k: info[k] for k in ("n_chunks", "n_slices", "padded_entries", "far_entries", "window")},

@@ -313,51 +313,90 @@ __device__ __forceinline__ unsigned lds_id_addr(unsigned dword, unsigned base /*
     return a;
 }
 __device__ __forceinline__ double lds_ld(unsigned a) { return *reinterpret_cast<lds_cdouble *>(a); }
-// the LDS byte addresses of the 12 ids of one int4 (addresses first, then the loads back to back, then the adds: the
-// asm statements would otherwise serialise address -> load -> wait -> add per entry)
-__device__ __forceinline__ void lds_addr12(const int4 t, unsigned base, unsigned (&a)[12]) {
-    const unsigned d0 = (unsigned)t.x, d1 = (unsigned)t.y, d2 = (unsigned)t.z, d3 = (unsigned)t.w;
+// the LDS byte addresses of 6 of the 12 ids of one int4 (H = 0: fields of .x .y, H = 1: of .z .w).  Addresses first,
+// then the loads back to back, then the adds: the asm statements would otherwise serialise address -> load -> wait ->
+// add per entry.  BATCH = 12 keeps a whole int4 in flight (36 temporaries), BATCH = 6 half of it (18).
+template <int H>
+__device__ __forceinline__ void lds_addr6(const int4 t, unsigned base, unsigned (&a)[6]) {
+    const unsigned d0 = (unsigned)(H ? t.z : t.x), d1 = (unsigned)(H ? t.w : t.y);
     a[0] = lds_id_addr<0>(d0, base); a[1] = lds_id_addr<1>(d0, base); a[2] = lds_id_addr<2>(d0, base);
     a[3] = lds_id_addr<0>(d1, base); a[4] = lds_id_addr<1>(d1, base); a[5] = lds_id_addr<2>(d1, base);
-    a[6] = lds_id_addr<0>(d2, base); a[7] = lds_id_addr<1>(d2, base); a[8] = lds_id_addr<2>(d2, base);
-    a[9] = lds_id_addr<0>(d3, base); a[10] = lds_id_addr<1>(d3, base); a[11] = lds_id_addr<2>(d3, base);
 }
 
 // E-step sums of up to 8 forward columns held in registers (n is wave-uniform); one int4 = this lane's 12 rows
+template <int BATCH = 12>
 __device__ __forceinline__ void fwd_sum_regs(const int4 (&q)[8], int n, unsigned th_base, double (&S)[kRPL]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         if (j < n) {
-            unsigned a[12];
-            double v[12];
-            lds_addr12(q[j], th_base, a);
+            if (BATCH == 12) {
+                unsigned a0[6], a1[6];
+                double v[12];
+                lds_addr6<0>(q[j], th_base, a0); lds_addr6<1>(q[j], th_base, a1);
 #pragma unroll
-            for (int i = 0; i < 12; i++) v[i] = lds_ld(a[i]);
+                for (int i = 0; i < 6; i++) { v[i] = lds_ld(a0[i]); }
 #pragma unroll
-            for (int i = 0; i < 12; i++) S[i] += v[i];
+                for (int i = 0; i < 6; i++) { v[6 + i] = lds_ld(a1[i]); }
+#pragma unroll
+                for (int i = 0; i < 12; i++) S[i] += v[i];
+            } else {
+                unsigned a[6];
+                double v[6];
+                lds_addr6<0>(q[j], th_base, a);
+#pragma unroll
+                for (int i = 0; i < 6; i++) v[i] = lds_ld(a[i]);
+#pragma unroll
+                for (int i = 0; i < 6; i++) S[i] += v[i];
+                lds_addr6<1>(q[j], th_base, a);
+#pragma unroll
+                for (int i = 0; i < 6; i++) v[i] = lds_ld(a[i]);
+#pragma unroll
+                for (int i = 0; i < 6; i++) S[6 + i] += v[i];
+            }
         }
     }
 }
 
 // M-step of up to 8 backward segments of one lane ({column, 11 row ids} each).  A lane's segments are consecutive
 // in column order: the running sum stays in a register and goes to the LDS accumulator when the column changes.
+template <int BATCH = 12>
 __device__ __forceinline__ void bwd_sum_regs(const int4 (&q)[8], int n, unsigned ws_base, double *acc_w, unsigned &cur, double &part) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         if (j < n) {
-            unsigned a[12];
-            double v[12];
-            lds_addr12(q[j], ws_base, a);
-#pragma unroll
-            for (int i = 1; i < 12; i++) v[i] = lds_ld(a[i]);
             const unsigned col = id_off((unsigned)q[j].x, 0);
+            double sum;
+            if (BATCH == 12) {
+                unsigned a0[6], a1[6];
+                double v[12];
+                lds_addr6<0>(q[j], ws_base, a0); lds_addr6<1>(q[j], ws_base, a1);
+#pragma unroll
+                for (int i = 1; i < 6; i++) v[i] = lds_ld(a0[i]);
+#pragma unroll
+                for (int i = 0; i < 6; i++) v[6 + i] = lds_ld(a1[i]);
+                double s0 = v[1] + v[2], s1 = v[3] + v[4], s2 = v[5] + v[6], s3 = v[7] + v[8];
+                s0 += v[9]; s1 += v[10]; s2 += v[11];
+                sum = (s0 + s1) + (s2 + s3);
+            } else {
+                unsigned a[6];
+                double v[6];
+                lds_addr6<0>(q[j], ws_base, a);
+#pragma unroll
+                for (int i = 1; i < 6; i++) v[i] = lds_ld(a[i]);
+                double s0 = v[1] + v[2], s1 = v[3] + v[4];
+                s0 += v[5];
+                lds_addr6<1>(q[j], ws_base, a);
+#pragma unroll
+                for (int i = 0; i < 6; i++) v[i] = lds_ld(a[i]);
+                s0 += v[0]; s1 += v[1];
+                double s2 = v[2] + v[3], s3 = v[4] + v[5];
+                sum = (s0 + s1) + (s2 + s3);
+            }
             if (col != cur) {
                 if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
                 cur = col; part = 0.0;
             }
-            double s0 = v[1] + v[2], s1 = v[3] + v[4], s2 = v[5] + v[6], s3 = v[7] + v[8];
-            s0 += v[9]; s1 += v[10]; s2 += v[11];
-            part += (s0 + s1) + (s2 + s3);
+            part += sum;
         }
     }
 }
@@ -515,11 +554,13 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_pass_tiled_pair: the same pass, two tiles per workgroup, software-pipelined by hand.  In k_pass_tiled a wave has
+// k_pass_tiled_multi: the same pass, N tiles per workgroup, software-pipelined by hand.  In k_pass_tiled a wave has
 // loads in flight only at its start (~20 % of its life); with four workgroups per CU there is often nobody loading and
-// the CU's share of HBM idles.  Here the forward registers are refilled with tile 1's columns as soon as tile 0's E-step
-// has consumed them, the backward registers after tile 0's M-step, and tile 1's dictionary values are requested before
-// tile 0's M-step: tile 1's HBM round trip hides behind tile 0's LDS work.
+// the CU's share of HBM idles.  Here the forward registers are refilled with the next tile's columns as soon as the
+// E-step has consumed them, the backward registers after the M-step, and the next dictionary is requested before the
+// M-step: the next tile's HBM round trip hides behind this tile's LDS work.  Measured on config 3: N = 2 0.218 ms,
+// N = 3 0.224, N = 4 0.242 (fewer, longer workgroups: the tail grows), a persistent loop 0.251 (hipcc spills the
+// loop-carried register arrays); one tile per workgroup 0.225.
 // ------------------------------------------------------------------------------------------------
 struct TileWave {           // what one wave needs to know about its slice of a tile (all wave-uniform but e/b)
     const int4 *e, *b;
@@ -576,7 +617,7 @@ __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], siz
     for (int j0 = 0; j0 < W.k; j0 += 8) {
         const int n0 = W.k - j0 < 8 ? W.k - j0 : 8;
         if (j0) load8_clamped(A, W.e + (size_t)j0 * 64, n0);
-        fwd_sum_regs(A, n0, th_base, S);
+        fwd_sum_regs<6>(A, n0, th_base, S);
     }
     if (WEIGHTED) {
 #pragma unroll
@@ -601,7 +642,7 @@ __device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], con
     for (int j0 = 0; j0 < W.m; j0 += 8) {
         const int n0 = W.m - j0 < 8 ? W.m - j0 : 8;
         if (j0) load8_clamped(B, W.b + (size_t)j0 * 64, n0);
-        bwd_sum_regs(B, n0, ws_base, acc_w, cur, part);
+        bwd_sum_regs<6>(B, n0, ws_base, acc_w, cur, part);
     }
     if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
     for (unsigned q = lane; q < W.coo_n; q += 64) {
@@ -621,59 +662,66 @@ __device__ __forceinline__ void tile_flush(int nd, const int (&tid_d)[4], const 
     }
 }
 
-template <bool WEIGHTED, int MODE>
-__global__ __launch_bounds__(kTiledThreads, 3) void k_pass_tiled_pair(const Tile *__restrict__ tiles, int n_tiles, const uint32_t *__restrict__ fwd,
-                                                                   const uint32_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
-                                                                   const int32_t *__restrict__ far_tid, const int32_t *__restrict__ wgt,
-                                                                   const double *__restrict__ theta, double *__restrict__ acc,
-                                                                   double *__restrict__ ll_out) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *th_w = lds, *acc_w = lds + kTiledDictPad;
-    __shared__ double red[kTiledThreads / 64];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;
-    const int i0 = blockIdx.x, i1 = blockIdx.x + gridDim.x;
-    const bool has1 = i1 < n_tiles;
-    const Tile T0 = tiles[i0];
-    const Tile T1 = tiles[has1 ? i1 : i0];
-    const TileWave W0 = tile_wave(T0, wave, lane, fwd, bwd);
+struct TileEnv {            // per-launch constants of the multi-tile kernel
+    const Tile *tiles; int n_tiles, stride;
+    const uint32_t *fwd, *bwd, *coo; const int32_t *far_tid, *wgt; const double *theta; double *acc;
+    double *th_w, *acc_w, *w_s; int lane, wave;
+};
+// stage I of N: tile `it` is in the registers (A, B in flight or landed, dictionary values in thv); while it is being
+// worked on, tile it + stride is requested into the registers as they fall free.  Straight-line code, no loop: hipcc
+// keeps loop-carried register arrays of this size in scratch.
+template <bool WEIGHTED, int MODE, int I, int N>
+__device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const Tile &T, const TileWave &W, int4 (&A)[8], int4 (&B)[8],
+                                            double (&thv)[4], const int (&tid)[4], double &ll) {
+    // a thread rewrites only the dictionary slots it flushed at the end of the previous stage
+    tile_dict_store(W.nd, thv, V.th_w, V.acc_w);
+    const int in = it + V.stride;
+    const bool has_next = (I + 1 < N) && in < V.n_tiles;
+    const Tile Tn = V.tiles[has_next ? in : it];
+    __syncthreads();
+    if (W.has_slice)
+        tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)V.wave * emsar::kTileSliceRows + V.lane, V.wgt, V.th_w, V.w_s, V.lane, ll);
+    const TileWave Wn = tile_wave(Tn, V.wave, V.lane, V.fwd, V.bwd);
+    int tidn[4] = {-1, -1, -1, -1};
+    if (has_next) {
+        if (Wn.has_slice) load8_clamped(A, Wn.e, Wn.k < 8 ? Wn.k : 8);
+        tile_dict_issue(Tn, Wn.nd, V.far_tid, V.theta, thv, tidn);
+    }
+    if (W.has_slice) tile_m_step(W, B, V.coo, V.w_s, V.acc_w, V.lane);
+    if (has_next && Wn.has_slice && Wn.m > 0) load8_clamped(B, Wn.b, Wn.m < 8 ? Wn.m : 8);
+    __syncthreads();
+    tile_flush(W.nd, tid, V.acc_w, V.acc);
+    if constexpr (I + 1 < N) {
+        if (has_next) tiled_stage<WEIGHTED, MODE, I + 1, N>(V, in, Tn, Wn, A, B, thv, tidn, ll);
+    }
+}
 
-    double thv[4]; int tid0[4], tid1[4];
+template <bool WEIGHTED, int MODE, int N>
+__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Tile *__restrict__ tiles, int n_tiles, const uint32_t *__restrict__ fwd,
+                                                                    const uint32_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
+                                                                    const int32_t *__restrict__ far_tid, const int32_t *__restrict__ wgt,
+                                                                    const double *__restrict__ theta, double *__restrict__ acc,
+                                                                    double *__restrict__ ll_out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double red[kTiledThreads / 64];
+    TileEnv V;
+    V.tiles = tiles; V.n_tiles = n_tiles; V.stride = (int)gridDim.x; V.fwd = fwd; V.bwd = bwd; V.coo = coo; V.far_tid = far_tid; V.wgt = wgt;
+    V.theta = theta; V.acc = acc;
+    V.lane = threadIdx.x & 63;
+    V.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    V.th_w = lds; V.acc_w = lds + kTiledDictPad; V.w_s = lds + 2 * kTiledDictPad + V.wave * kTiledWr;
+    const Tile T = tiles[blockIdx.x];
+    const TileWave W = tile_wave(T, V.wave, V.lane, fwd, bwd);
+    double thv[4]; int tid[4];
     int4 A[8], B[8];
-    tile_dict_issue(T0, W0.nd, far_tid, theta, thv, tid0);
-    if (W0.has_slice) {
-        load8_clamped(A, W0.e, W0.k < 8 ? W0.k : 8);
-        if (W0.m > 0) load8_clamped(B, W0.b, W0.m < 8 ? W0.m : 8);
+    tile_dict_issue(T, W.nd, far_tid, theta, thv, tid);
+    if (W.has_slice) {
+        load8_clamped(A, W.e, W.k < 8 ? W.k : 8);
+        if (W.m > 0) load8_clamped(B, W.b, W.m < 8 ? W.m : 8);
     }
-    tile_dict_store(W0.nd, thv, th_w, acc_w);
-    if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;
-    __syncthreads();
+    if (V.lane < 8) V.w_s[emsar::kTileSliceRows + V.lane] = 0.0;
     double ll = 0.0;
-    if (W0.has_slice)
-        tile_e_step<WEIGHTED, MODE>(W0, A, (size_t)T0.row_base + (size_t)wave * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
-    // tile 1: forward columns into the registers the E-step has just released, dictionary values requested now
-    const TileWave W1 = tile_wave(T1, wave, lane, fwd, bwd);
-    if (has1) {
-        if (W1.has_slice) load8_clamped(A, W1.e, W1.k < 8 ? W1.k : 8);
-        tile_dict_issue(T1, W1.nd, far_tid, theta, thv, tid1);
-    }
-    if (W0.has_slice) tile_m_step(W0, B, coo, w_s, acc_w, lane);
-    if (has1 && W1.has_slice && W1.m > 0) load8_clamped(B, W1.b, W1.m < 8 ? W1.m : 8);
-    __syncthreads();
-    tile_flush(W0.nd, tid0, acc_w, acc);
-    if (has1) {
-        // a thread rewrites only the dictionary slots it has just flushed; the barrier orders the new dictionary
-        // before the other waves' reads
-        tile_dict_store(W1.nd, thv, th_w, acc_w);
-        __syncthreads();
-        if (W1.has_slice) {
-            tile_e_step<WEIGHTED, MODE>(W1, A, (size_t)T1.row_base + (size_t)wave * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
-            tile_m_step(W1, B, coo, w_s, acc_w, lane);
-        }
-        __syncthreads();
-        tile_flush(W1.nd, tid1, acc_w, acc);
-    }
+    tiled_stage<WEIGHTED, MODE, 0, N>(V, (int)blockIdx.x, T, W, A, B, thv, tid, ll);
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);
         if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
@@ -1100,7 +1148,7 @@ struct emsar_hip_ctx {
     int64_t bytes_formula = 0, bytes_stored = 0;
     int64_t tl_fwd_slots = 0, tl_n_fslices = 0;
     double count_floor = 0.0;    // stopping-rule floor in reads for the current solve (emsar_em_params.count_floor)
-    bool tiled_pair = false;     // two tiles per workgroup (k_pass_tiled_pair)
+    int tiled_multi = 2;         // 2: two tiles per workgroup, software-pipelined (k_pass_tiled_multi); 0: one (k_pass_tiled)
     const uint8_t *delta_mask = nullptr;   // d_kind while the streaming solve runs next to resident sets
     // set-resident solver (sets.hpp): host copy of the CSR and of the sample's row weights, built lazily by solve
     std::vector<uint64_t> h_row_ptr;
@@ -1175,17 +1223,20 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
 #define LAUNCH_T(WT, MD)                                                                                          \
     hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, ctx->d_tiles, ctx->d_fwd, ctx->d_bwd,   \
                        ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out)
-#define LAUNCH_P(WT, MD)                                                                                          \
-    hipLaunchKernelGGL((k_pass_tiled_pair<WT, MD>), dim3((unsigned)((ctx->n_tiles + 1) / 2)), block, lds, ctx->stream, ctx->d_tiles,  \
+#define LAUNCH_PN(WT, MD, NN)                                                                                     \
+    hipLaunchKernelGGL((k_pass_tiled_multi<WT, MD, NN>), dim3((unsigned)((ctx->n_tiles + NN - 1) / NN)), block, lds, ctx->stream, ctx->d_tiles,  \
                        (int)ctx->n_tiles, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, theta, acc, ll_out)
+#define LAUNCH_P(WT, MD) LAUNCH_PN(WT, MD, 2)
             if (mode == MODE_SCATTER) LAUNCH_T(false, MODE_SCATTER);
-            else if (ctx->tiled_pair) {
-                if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_P(true, MODE_EM_LL); else LAUNCH_P(true, MODE_EM); }
-                else { if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM); }
+            else if (ctx->tiled_multi >= 2 && !ctx->weighted) {
+                // two tiles per workgroup, software-pipelined: +3 % on config 3.  Unweighted rows only: with the row
+                // weights in registers as well the two-tile body does not fit 128 VGPRs (0.218 vs 0.179 ms measured)
+                if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM);
             }
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
             else { if (mode == MODE_EM_LL) LAUNCH_T(false, MODE_EM_LL); else LAUNCH_T(false, MODE_EM); }
 #undef LAUNCH_P
+#undef LAUNCH_PN
 #undef LAUNCH_T
         }
         if (ctx->n_left > 0) {   // rows too long for a tile: generic CSR kernel on the leftover
@@ -1453,10 +1504,10 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
 #define SETLDS_T(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             SETLDS_T(false, MODE_EM); SETLDS_T(false, MODE_EM_LL); SETLDS_T(true, MODE_EM); SETLDS_T(true, MODE_EM_LL); SETLDS_T(false, MODE_SCATTER);
 #undef SETLDS_T
-#define SETLDS_P(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_pair<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-            SETLDS_P(false, MODE_EM); SETLDS_P(false, MODE_EM_LL); SETLDS_P(true, MODE_EM); SETLDS_P(true, MODE_EM_LL);
+#define SETLDS_P(WT, MD, NN) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_multi<WT, MD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+            SETLDS_P(false, MODE_EM, 2); SETLDS_P(false, MODE_EM_LL, 2);
 #undef SETLDS_P
-            { const char *pe = getenv("EMSAR_HIP_TILED_PAIR"); ctx->tiled_pair = pe && atoi(pe) != 0; }
+            { const char *pe = getenv("EMSAR_HIP_TILED_MULTI"); ctx->tiled_multi = pe ? atoi(pe) : 2; }
         } else if (layout == EMSAR_LAYOUT_WINDOWED) {
             const char *wenv = getenv("EMSAR_HIP_WINDOW");
             int window = wenv ? atoi(wenv) : kDefaultWindow;
