@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads and transcripts (debug only)")
     ap.add_argument("--layout", default="auto", choices=["auto", "csr", "windowed", "tiled"])
@@ -144,6 +144,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(s, nnz)
     dev.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["time_to_mle"] = time_to_mle(local_rank)
     group.close()
     if rank == 0:
         print(json.dumps(out))
@@ -168,6 +170,45 @@ def cpu_baseline(s, nnz):
             break
     return {"value": n / dt, "unit": "iter/s", "cores": cores, "kind": "port",
             "sample": "%d EM passes of the oracle's OpenMP EM over the same %d-read matrix (nnz %d)" % (n, s["n_reads"], nnz)}
+
+
+def time_to_mle(device):
+    """SURVEY.md 8d, headline reported the second way: wall time to the MLE of a SEGMENT-level problem (what the
+    reference actually solves: families of transcripts, thousands of independent sets) -- emsar_hip_solve against the
+    oracle's port of the reference's own algorithm (pattern search per set, static split over threads:
+    MLE / run_MLE_threads, emsar_functions.c:2977-3126).  Not part of `value`."""
+    import numpy as np
+    import oracle as O
+    from emsar_amd import EmsarHip, synth
+    rng = np.random.default_rng(11)
+    sizes = np.minimum(rng.zipf(1.6, size=40000), 60)
+    sizes = sizes[np.cumsum(sizes) <= 100000]
+    n_tx, rp, ci, _ = synth.family_matrix([int(x) for x in sizes], rows_per_tid=3, seed=11, dup=0.0)
+    E = rng.uniform(0.5, 2.0, size=len(rp) - 1)
+    # counts drawn from the model itself: theta* ~ LogNormal(0, 2) with 30 % zeros, R_c ~ Poisson(E_c * sum theta*)
+    theta_true = np.where(rng.random(n_tx) < 0.3, 0.0, rng.lognormal(0.0, 2.0, size=n_tx))
+    R = rng.poisson(E * np.add.reduceat(theta_true[ci], rp[:-1].astype(np.int64))).astype(np.int32)
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), int(os.environ.get("EMSAR_CPU_THREADS", "16")))
+    m = O.Csr(n_tx, rp, ci, R=R, E=E, L=E)
+    n_sets, cs, ts, _ = m.components()
+    t0 = time.perf_counter()
+    th_ref, sweeps = m.mle_pattern_search(cs, n_sets, seed=1, n_threads=cores)
+    cpu_s = time.perf_counter() - t0
+    dev = EmsarHip(device)
+    dev.upload_structure(n_tx, rp, ci)
+    dev.upload_sample(R, E, None)
+    dev.solve(max_iter=200000, tol=1e-10)                       # first call: finds and packs the sets (host), warms up
+    t0 = time.perf_counter()
+    th, st = dev.solve(max_iter=200000, tol=1e-10)
+    gpu_s = time.perf_counter() - t0
+    dev.close()
+    F_ref, F = m.loglik(th_ref), m.loglik(th)
+    return {"workload": "segment-level synthetic: %d transcripts in %d families (Zipf 1.6, <= 60), %d segments, %d reads, %d connected sets"
+                        % (n_tx, len(sizes), len(R), int(R.sum()), n_sets),
+            "gpu_s": gpu_s, "gpu_kernel_ms": st.kernel_ms, "gpu_em_passes_slowest_set": st.set_passes_max, "gpu_sets_resident": st.sets_resident,
+            "gpu_sets_streamed": st.sets_streamed, "gpu_converged": bool(st.converged), "set_packing_host_ms": st.sets_build_ms,
+            "cpu_reference_algorithm_s": cpu_s, "cpu_cores": cores, "cpu_kind": "port", "cpu_sweeps": int(sweeps),
+            "speedup": cpu_s / gpu_s, "loglik_gpu_minus_cpu": F - F_ref, "loglik": F}
 
 
 if __name__ == "__main__":

@@ -941,7 +941,12 @@ __device__ __forceinline__ double set_em_estep(const SetLds &L, const double *x)
     for (int j = threadIdx.x; j < L.nr; j += THREADS) {
         double S = 0.0;
         const int b = L.rp[j], e = L.rp[j + 1];
-        for (int k = b; k < e; k++) S += x[L.ent[k]];
+        int k = b;
+        for (; k + 4 <= e; k += 4) {      // four independent index -> value chains in flight
+            const int i0 = L.ent[k], i1 = L.ent[k + 1], i2 = L.ent[k + 2], i3 = L.ent[k + 3];
+            S += (x[i0] + x[i1]) + (x[i2] + x[i3]);
+        }
+        for (; k < e; k++) S += x[L.ent[k]];
         const double r = L.rw[j];
         const bool live = S > 0.0;
         L.w[j] = live ? r / S : 0.0;
@@ -953,7 +958,12 @@ __device__ __forceinline__ double set_em_estep(const SetLds &L, const double *x)
 __device__ __forceinline__ double set_em_acc(const SetLds &L, int i) {
     double a = 0.0;
     const int b = L.cp[i], e = L.cp[i + 1];
-    for (int k = b; k < e; k++) a += L.w[L.crow[k]];
+    int k = b;
+    for (; k + 4 <= e; k += 4) {
+        const int j0 = L.crow[k], j1 = L.crow[k + 1], j2 = L.crow[k + 2], j3 = L.crow[k + 3];
+        a += (L.w[j0] + L.w[j1]) + (L.w[j2] + L.w[j3]);
+    }
+    for (; k < e; k++) a += L.w[L.crow[k]];
     return a;
 }
 __device__ __forceinline__ double set_em_update(double x, double a, double u, double dn) {

@@ -175,8 +175,13 @@ inline int build_sets(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, con
             stream();
             continue;
         }
+        // class by LDS footprint AND by parallelism: a pass is a chain of dependent LDS accesses per row / per
+        // transcript, so a set wants about one row and one transcript per thread
         int cls = 0;
         while (bytes > kSetLdsCap[cls]) cls++;
+        const size_t par = std::max(nt, nr);
+        if (par > 64 && cls < 1) cls = 1;
+        if (par > 512 && cls < 2) cls = 2;
         SetDesc d;
         d.tid_off = (uint32_t)out.g_tid.size(); d.row_off = (uint32_t)out.row_w.size(); d.ent_off = (uint32_t)out.ent.size();
         d.rp_off = (uint32_t)out.rp.size(); d.cp_off = (uint32_t)out.cp.size();
