@@ -1077,6 +1077,43 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
     if (threadIdx.x == 0) { stat[blockIdx.x].passes = passes; stat[blockIdx.x].converged = converged; stat[blockIdx.x].delta = delta; }
 }
 
+// EUMA [rows][nfl] -> [nfl][rows] through a 64 x 64 LDS tile (once per rsh)
+__global__ __launch_bounds__(256) void k_transpose_i32(int64_t n_rows, int nfl, const int32_t *__restrict__ in, int32_t *__restrict__ out) {
+    __shared__ int32_t tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = (int)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+        const int64_t r = r0 + j; const int c = c0 + tx;
+        tile[j][tx] = (r < n_rows && c < nfl) ? in[(size_t)r * (size_t)nfl + (size_t)c] : 0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        const int c = c0 + j; const int64_t r = r0 + tx;
+        if (r < n_rows && c < nfl) out[(size_t)c * (size_t)n_rows + (size_t)r] = tile[tx][j];
+    }
+}
+// compute_adjEUMA (emsar_functions.c:2517-2523): one lane per row, fragment lengths in ascending order, product and sum
+// rounded separately (no FMA) -- bit-identical to the reference's scalar loop; every load is a coalesced 256 B per wave
+__global__ __launch_bounds__(256) void k_adj_euma(int64_t n_rows, int nfl, const int32_t *__restrict__ euma_t, const double *__restrict__ wf,
+                                                  double *__restrict__ out) {
+#pragma clang fp contract(off)   // hipcc fuses a + x*y into an FMA by default (one rounding instead of the reference's two);
+                                 // plain operators: the __dmul_rn / __dadd_rn wrappers carry their own contraction flag
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    double a = 0.0;
+    int i = 0;
+    for (; i + 8 <= nfl; i += 8) {
+        int32_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) e[j] = euma_t[(size_t)(i + j) * (size_t)n_rows + (size_t)r];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const double p = wf[i + j] * (double)e[j]; a = a + p; }
+    }
+    for (; i < nfl; i++) { const double p = wf[i] * (double)euma_t[(size_t)i * (size_t)n_rows + (size_t)r]; a = a + p; }
+    out[r] = a;
+}
+
 // transcripts outside every multi-transcript set: theta = (reads of its single-transcript rows) / den
 __global__ void k_closed_form(int n, const uint8_t *__restrict__ kind, const double *__restrict__ usum,
                               const double *__restrict__ den, double *__restrict__ theta) {
@@ -1171,6 +1208,8 @@ struct emsar_hip_ctx {
     uint16_t *d_srp = nullptr, *d_sent = nullptr, *d_scp = nullptr, *d_scrow = nullptr;
     uint8_t *d_kind = nullptr;
     double sets_build_ms = 0.0;
+    // compute_adjEUMA on the device
+    int32_t *d_euma_t = nullptr; int32_t nfl = 0; double *d_wf = nullptr, *d_adj = nullptr;
 };
 
 namespace {
@@ -1207,6 +1246,7 @@ void free_sets(emsar_hip_ctx *ctx) {
 
 void free_structure(emsar_hip_ctx *ctx) {
     free_sets(ctx);
+    dfree(ctx->d_euma_t); dfree(ctx->d_wf); dfree(ctx->d_adj); ctx->d_euma_t = nullptr; ctx->d_wf = ctx->d_adj = nullptr; ctx->nfl = 0;
     std::vector<uint64_t>().swap(ctx->h_row_ptr); std::vector<int32_t>().swap(ctx->h_col); std::vector<int32_t>().swap(ctx->h_wgt);
     dfree(ctx->d_row_ptr); dfree(ctx->d_col); dfree(ctx->d_chunks); dfree(ctx->d_slice_off); dfree(ctx->d_ent);
     ctx->d_row_ptr = nullptr; ctx->d_col = nullptr; ctx->d_chunks = nullptr; ctx->d_slice_off = nullptr; ctx->d_ent = nullptr;
@@ -1861,6 +1901,46 @@ int emsar_hip_normalise(emsar_hip_ctx *ctx, const double *mean_fpkm, const doubl
     HIPCHK(hipMemcpyAsync(ir_out, ctx->d_acc, B, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(iri_out, ctx->d_itmp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, B, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_upload_euma(emsar_hip_ctx *ctx, const int32_t *euma, int32_t nfl) {
+    if (!ctx || !euma || nfl <= 0) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_structure) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    dfree(ctx->d_euma_t); dfree(ctx->d_wf); dfree(ctx->d_adj); ctx->d_euma_t = nullptr; ctx->d_wf = ctx->d_adj = nullptr; ctx->nfl = 0;
+    const size_t n = (size_t)ctx->n_rows * (size_t)nfl;
+    int32_t *tmp = nullptr;
+    HIPCHK(hipMalloc(&ctx->d_euma_t, std::max<size_t>(n, 1) * 4));
+    HIPCHK(hipMalloc(&ctx->d_wf, (size_t)nfl * 8));
+    HIPCHK(hipMalloc(&ctx->d_adj, std::max<size_t>((size_t)ctx->n_rows, 1) * 8));
+    if (n) {
+        HIPCHK(hipMalloc(&tmp, n * 4));
+        hipError_t e = hipMemcpyAsync(tmp, euma, n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            dim3 grid((unsigned)((ctx->n_rows + 63) / 64), (unsigned)((nfl + 63) / 64));
+            hipLaunchKernelGGL(k_transpose_i32, grid, dim3(256), 0, ctx->stream, ctx->n_rows, (int)nfl, tmp, ctx->d_euma_t);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+        HIPCHK(e);
+    }
+    ctx->nfl = nfl;
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_adj_euma(emsar_hip_ctx *ctx, const double *wf, double *out) {
+    if (!ctx || !wf || !out) return EMSAR_HIP_ERR_ARG;
+    if (!ctx->have_structure || ctx->nfl <= 0) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->n_rows == 0) return EMSAR_HIP_OK;
+    HIPCHK(hipMemcpyAsync(ctx->d_wf, wf, (size_t)ctx->nfl * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_adj_euma, dim3((unsigned)((ctx->n_rows + 255) / 256)), dim3(256), 0, ctx->stream, ctx->n_rows, (int)ctx->nfl,
+                       ctx->d_euma_t, ctx->d_wf, ctx->d_adj);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, ctx->d_adj, (size_t)ctx->n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return EMSAR_HIP_OK;
 }

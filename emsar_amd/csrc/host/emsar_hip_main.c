@@ -62,13 +62,26 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i) {
     double t0 = now_s();
     rc = emsar_count_alignments(r, cfg->aln[i], &cfg->ao, &cnt, err, sizeof err);
     w->parse_s[i] = now_s() - t0;
+    /* compute_adjEUMA (emsar_main.c:403): L = EUMA . Wf on the device, bit-identical to the host loop */
+    double *Ldev = NULL;
+    if (rc == 0) {
+        double *wf = (double *)malloc(sizeof(double) * (size_t)r->nfl);
+        Ldev = (double *)malloc(sizeof(double) * (size_t)(r->n_rows > 0 ? r->n_rows : 1));
+        if (!wf || !Ldev) rc = EMSAR_HOST_ERR_OOM;
+        else if (emsar_model_wf(r, cnt, wf) == EMSAR_HOST_OK) {
+            int hrc = emsar_hip_adj_euma(ctx, wf, Ldev);
+            if (hrc) { snprintf(err, sizeof err, "adj_euma: %s (%s)", emsar_hip_strerror(hrc), emsar_hip_last_error(ctx)); rc = EMSAR_HOST_ERR_IO; }
+        } else { free(Ldev); Ldev = NULL; }            /* model_build reports the empty fragment-length window */
+        free(wf);
+    }
     /* model preparation in sample order (EUMAcut carries over) */
     pthread_mutex_lock(w->mu);
     while (*w->next_model != i) pthread_cond_wait(w->cv, w->mu);
-    if (rc == 0) rc = emsar_model_build(r, cnt, cfg->delta, w->eumacut, &m, err, sizeof err);
+    if (rc == 0) rc = emsar_model_build_L(r, cnt, cfg->delta, w->eumacut, Ldev, &m, err, sizeof err);
     (*w->next_model)++;
     pthread_cond_broadcast(w->cv);
     pthread_mutex_unlock(w->mu);
+    free(Ldev);
     if (rc) { fprintf(stderr, "alnfile[%d]=%s: %s\n", i, cfg->aln[i], err); goto done; }
     if (cfg->verbose > 0)
         fprintf(stdout, "alnfile[%d]=%s  reads=%lld (seen %lld, >k %lld, bad fraglen %lld, discrepant %lld, no segment %lld)  sets=%d  gpu=%d\n",
@@ -120,6 +133,7 @@ static void *worker_main(void *a) {
     emsar_hip_ctx *ctx = NULL;
     int rc = emsar_hip_create(&ctx, w->device);
     if (rc == 0) rc = emsar_hip_upload_structure(ctx, w->rsh->n_rows, w->rsh->n_tx, w->rsh->row_ptr, w->rsh->col_idx, EMSAR_LAYOUT_AUTO);
+    if (rc == 0) rc = emsar_hip_upload_euma(ctx, w->rsh->euma, w->rsh->nfl);     /* once per rsh: compute_adjEUMA runs on the device */
     if (rc) fprintf(stderr, "GPU %d: %s\n", w->device, emsar_hip_strerror(rc));
     for (int i = w->worker; i < w->cfg->n_aln; i += w->n_workers) {
         if (rc) {   /* keep the ordered hand-over alive so the other workers are not stuck */

@@ -87,6 +87,11 @@ typedef struct {
 /* eumacut_io persists across samples like the reference's global (never reset between -M samples). */
 int  emsar_model_build(const emsar_rsh *r, const emsar_counts *c, int delta, double *eumacut_io, emsar_model **out,
                        char *err, size_t errlen);
+/* the two halves separately, for callers that compute L_c = sum_i Wf[i] * EUMA_c[i] elsewhere (emsar_hip_adj_euma):
+ * model_wf fills wf[nfl] (error if no read falls inside the fragment-length range); build_L takes L (NULL = host loop) */
+int  emsar_model_wf(const emsar_rsh *r, const emsar_counts *c, double *wf);
+int  emsar_model_build_L(const emsar_rsh *r, const emsar_counts *c, int delta, double *eumacut_io, const double *L,
+                         emsar_model **out, char *err, size_t errlen);
 void emsar_model_free(emsar_model *m);
 
 /* mean/sd over rounds exactly as print_FPKMfinal does (sd = sqrt(sum sq/(n-1))/n; n = 1 gives NaN like the reference) */

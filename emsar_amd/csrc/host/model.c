@@ -19,8 +19,26 @@ static int32_t uf_find(int32_t *p, int32_t x) {
     return x;
 }
 
+int emsar_model_wf(const emsar_rsh *r, const emsar_counts *c, double *wf) {
+    /* the window [frag_min, frag_max] of the observed fragment-length histogram, normalised */
+    double sum = 0;
+    for (int i = 0; i < r->nfl; i++) {
+        int fl = i + r->frag_min;
+        wf[i] = (fl < c->n_frag) ? (double)c->frag_counts[fl] : 0.0;
+        sum += wf[i];
+    }
+    if (!(sum > 0)) return EMSAR_HOST_ERR_FORMAT;
+    for (int i = 0; i < r->nfl; i++) wf[i] /= sum;
+    return EMSAR_HOST_OK;
+}
+
 int emsar_model_build(const emsar_rsh *r, const emsar_counts *c, int delta, double *eumacut_io, emsar_model **out,
                       char *err, size_t errlen) {
+    return emsar_model_build_L(r, c, delta, eumacut_io, NULL, out, err, errlen);
+}
+
+int emsar_model_build_L(const emsar_rsh *r, const emsar_counts *c, int delta, double *eumacut_io, const double *L_pre,
+                        emsar_model **out, char *err, size_t errlen) {
     *out = NULL;
     emsar_model *m = (emsar_model *)calloc(1, sizeof(*m));
     if (!m) return EMSAR_HOST_ERR_OOM;
@@ -39,23 +57,16 @@ int emsar_model_build(const emsar_rsh *r, const emsar_counts *c, int delta, doub
     int rc = EMSAR_HOST_OK;
     if (!m->Wf || !m->L || !m->E || !m->E_solver || !m->CS || !m->TS || !par || !sid_of_root || !cnt) { rc = EMSAR_HOST_ERR_OOM; goto done; }
 
-    /* Wf: the window [frag_min, frag_max] of the observed fragment-length histogram, normalised */
-    double sum = 0;
-    for (int i = 0; i < nfl; i++) {
-        int fl = i + r->frag_min;
-        m->Wf[i] = (fl < c->n_frag) ? (double)c->frag_counts[fl] : 0.0;
-        sum += m->Wf[i];
-    }
-    if (!(sum > 0)) {
+    if (emsar_model_wf(r, c, m->Wf) != EMSAR_HOST_OK) {
         if (err) snprintf(err, errlen, "no read inside the fragment-length range [%d,%d]", r->frag_min, r->frag_max);
         rc = EMSAR_HOST_ERR_FORMAT; goto done;
     }
-    for (int i = 0; i < nfl; i++) m->Wf[i] /= sum;
 
     const double scale_n = (double)c->total_reads / 1E6, scale_d = pow(10, delta);
     for (int64_t cid = 0; cid < C; cid++) {
         double a = 0;
-        if (r->has_node[cid]) {
+        if (L_pre) a = L_pre[cid];                     /* computed on the device (emsar_hip_adj_euma), same arithmetic */
+        else if (r->has_node[cid]) {
             const int32_t *e = r->euma + (size_t)cid * (size_t)nfl;
             for (int i = 0; i < nfl; i++) a += m->Wf[i] * (double)e[i];
         }

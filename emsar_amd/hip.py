@@ -18,7 +18,7 @@ SYMBOLS = [
     "emsar_hip_upload_structure", "emsar_hip_upload_sample", "emsar_hip_solve",
     "emsar_hip_reset_theta", "emsar_hip_set_theta", "emsar_hip_get_theta", "emsar_hip_run_passes",
     "emsar_hip_ieuma", "emsar_hip_normalise", "emsar_hip_get_info", "emsar_hip_layout_selfcheck",
-    "emsar_hip_layout_selfcheck_tiled", "emsar_hip_sets_selfcheck",
+    "emsar_hip_layout_selfcheck_tiled", "emsar_hip_sets_selfcheck", "emsar_hip_upload_euma", "emsar_hip_adj_euma",
 ]
 
 
@@ -86,6 +86,8 @@ def load_library():
     L.emsar_hip_get_info.argtypes = [vp, C.POINTER(Info)]
     L.emsar_hip_layout_selfcheck.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int32, C.c_int64, C.POINTER(Info)]
     L.emsar_hip_layout_selfcheck_tiled.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int, C.POINTER(Info)]
+    L.emsar_hip_upload_euma.argtypes = [vp, i32p, C.c_int32]
+    L.emsar_hip_adj_euma.argtypes = [vp, f64p, f64p]
     L.emsar_hip_sets_selfcheck.argtypes = [C.c_int64, C.c_int32, u64p, i32p, i32p, C.POINTER(SetsInfo)]
     _lib = L
     return L
@@ -203,6 +205,23 @@ class EmsarHip:
         out = np.zeros(self.n_tx)
         self._chk(self._L.emsar_hip_solve(self._h, C.byref(p), _p(out, C.c_double), C.byref(st)), "solve")
         return out, st
+
+    def upload_euma(self, euma):
+        """EUMA[n_rows][nfl] (int32, 0 where absent): once per rsh, after upload_structure."""
+        euma = _arr(euma, np.int32)
+        if euma.ndim != 2 or euma.shape[0] != self.n_rows:
+            raise ValueError("euma must be [n_rows][nfl]")
+        self.nfl = int(euma.shape[1])
+        self._chk(self._L.emsar_hip_upload_euma(self._h, _p(euma, C.c_int32), self.nfl), "upload_euma")
+
+    def adj_euma(self, wf):
+        """L_c = sum_i Wf[i] * EUMA_c[i] (compute_adjEUMA), bit-identical to the host loop."""
+        wf = _arr(wf, np.float64)
+        if wf.shape != (getattr(self, "nfl", -1),):
+            raise ValueError("wf must have nfl entries")
+        out = np.zeros(self.n_rows)
+        self._chk(self._L.emsar_hip_adj_euma(self._h, _p(wf, C.c_double), _p(out, C.c_double)), "adj_euma")
+        return out
 
     def reset_theta(self):
         self._chk(self._L.emsar_hip_reset_theta(self._h), "reset_theta")

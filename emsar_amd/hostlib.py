@@ -61,6 +61,9 @@ def lib():
         L.emsar_counts_free.restype = None
         L.emsar_model_build.argtypes = [C.POINTER(Rsh), C.POINTER(Counts), C.c_int, C.POINTER(C.c_double),
                                         C.POINTER(C.POINTER(Model)), C.c_char_p, C.c_size_t]
+        L.emsar_model_wf.argtypes = [C.POINTER(Rsh), C.POINTER(Counts), C.POINTER(C.c_double)]
+        L.emsar_model_build_L.argtypes = [C.POINTER(Rsh), C.POINTER(Counts), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.POINTER(Model)), C.c_char_p, C.c_size_t]
         L.emsar_model_free.argtypes = [C.POINTER(Model)]
         L.emsar_model_free.restype = None
         f64p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
@@ -119,11 +122,23 @@ class HostRsh:
             raise HostError("count_alignments rc=%d: %s" % (rc, err.value.decode()))
         return HostCounts(p)
 
-    def model(self, counts, delta=0, eumacut=0.0):
+    def wf(self, counts):
+        """Normalised fragment-length histogram of the sample (transfer_fraglendist_to_Wf)."""
+        out = np.zeros(self.nfl)
+        if lib().emsar_model_wf(self._p, counts._p, _dp(out)) != 0:
+            raise HostError("no read inside the fragment-length range")
+        return out
+
+    def model(self, counts, delta=0, eumacut=0.0, L=None):
+        """L = per-row adjEUMA computed elsewhere (EmsarHip.adj_euma); None = the host loop."""
         cut = C.c_double(eumacut)
         p = C.POINTER(Model)()
         err = C.create_string_buffer(512)
-        rc = lib().emsar_model_build(self._p, counts._p, delta, C.byref(cut), C.byref(p), err, 512)
+        if L is not None:
+            L = np.ascontiguousarray(L, dtype=np.float64)
+            if L.shape != (self.n_rows,):
+                raise ValueError("L must have n_rows entries")
+        rc = lib().emsar_model_build_L(self._p, counts._p, delta, C.byref(cut), None if L is None else _dp(L), C.byref(p), err, 512)
         if rc != 0:
             raise HostError("model_build rc=%d: %s" % (rc, err.value.decode()))
         return HostModel(p, cut.value)

@@ -136,6 +136,16 @@ int emsar_hip_ieuma(emsar_hip_ctx *ctx, const double *row_L /* n_rows */, double
 int emsar_hip_normalise(emsar_hip_ctx *ctx, const double *mean_fpkm, const double *ieuma, int64_t total_read_count,
                         double *tpm_out, double *ireadcount_out, int32_t *ireadcount_int_out);
 
+/* ---- per-sample effective lengths: compute_adjEUMA (emsar_functions.c:2517-2523) ----------------
+ * upload_euma: EUMA_c[i], the effective position counts per fragment length of every row (emsar.h:141, read from the rsh
+ *   by construct_rsh_from_rshfile, emsar_functions.c:1351-1510), row-major [n_rows][nfl], 0 where a row has no entry;
+ *   once per rsh, after upload_structure.  Stored transposed in HBM ([nfl][n_rows]) so that one lane owns one row.
+ * adj_euma: L_c = sum_i Wf[i] * (double)EUMA_c[i], i ascending, multiply and add rounded separately -- the reference's
+ *   loop, operation for operation, so L is bit-identical to the host's.  Wf = the sample's normalised fragment-length
+ *   histogram (transfer_fraglendist_to_Wf, emsar_functions.c:2503-2513).  HBM-bound: 4 * n_rows * nfl bytes per call. */
+int emsar_hip_upload_euma(emsar_hip_ctx *ctx, const int32_t *euma /* n_rows * nfl */, int32_t nfl);
+int emsar_hip_adj_euma(emsar_hip_ctx *ctx, const double *wf /* nfl */, double *adj_euma_out /* n_rows */);
+
 /* ---- introspection ------------------------------------------------------------------------------ */
 typedef struct {
     int64_t n_rows, nnz;

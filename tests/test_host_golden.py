@@ -159,3 +159,21 @@ def test_reader_error_paths(tmp_path):
     notbam.write_bytes(b"this is not a BAM file")
     with pytest.raises(HL.HostError):
         r.count(str(notbam), fmt=2)
+
+
+def test_model_with_precomputed_L_is_the_same_model(golden):
+    """The split the CLI uses: Wf on the host, L = EUMA . Wf elsewhere (emsar_hip_adj_euma), the rest from L."""
+    r, c, m = _host(golden)
+    wf = r.wf(c)
+    np.testing.assert_array_equal(wf, m.Wf)
+    L = np.zeros(r.n_rows)
+    for cid in range(r.n_rows):                                   # the reference's loop: i ascending, multiply then add
+        a = 0.0
+        for i in range(r.nfl):
+            a += wf[i] * float(r.euma[cid, i])
+        L[cid] = a
+    np.testing.assert_array_equal(L, m.L)
+    m2 = r.model(c, L=L)
+    for k in ("L", "E", "E_solver", "CS", "TS", "Wf"):
+        np.testing.assert_array_equal(getattr(m2, k), getattr(m, k))
+    assert m2.n_sets == m.n_sets
