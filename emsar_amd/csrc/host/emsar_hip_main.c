@@ -39,6 +39,7 @@ typedef struct {
     int n_round, delta, print_segments, verbose, accel, set_mode;
     double tol, count_floor; int max_iter;
     const char *stats_json;
+    const char *rsh_cache;      /* NULL = off, "" = <rsh>.bin, else the path */
 } config;
 
 typedef struct {
@@ -165,6 +166,7 @@ static void usage(const char *a0) {
             "  -d, --delta <d>         10^d scaling of the effective lengths (default 0)\n"
             "  -g, --print_segments    also write .segments\n"
             "      --count-floor <reads> stopping-rule floor in inferred reads (default 0 = off; e.g. 1e-3 for large samples)\n"
+            "      --rsh-cache[=file]    read the parsed index from a binary cache (default <rshfile>.bin), write it after a text parse\n"
             "      --streaming-only      do not split the problem into connected sets (every pass streams the whole matrix)\n"
             "      --gpus <n> / --device <d> / --plain / --stats-json <file> / -q / -v\n", a0);
 }
@@ -180,7 +182,7 @@ int main(int argc, char **argv) {
         {"print_segments", no_argument, 0, 'g'}, {"multisample", no_argument, 0, 'M'}, {"SAM", no_argument, 0, 'S'}, {"BAM", no_argument, 0, 'B'},
         {"verbose", no_argument, 0, 'v'}, {"no_verbose", no_argument, 0, 'q'}, {"gpus", required_argument, 0, 1000},
         {"device", required_argument, 0, 1001}, {"plain", no_argument, 0, 1002}, {"stats-json", required_argument, 0, 1003},
-        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005},
+        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005}, {"rsh-cache", optional_argument, 0, 1006},
         {"maxfraglen", required_argument, 0, 'F'}, {"minfraglen", required_argument, 0, 'f'}, {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "vqPs:p:F:f:n:e:d:gMSBk:i:I:", lo, NULL)) != -1) {
@@ -207,6 +209,7 @@ int main(int argc, char **argv) {
             case 1003: cfg.stats_json = optarg; break;
             case 1004: cfg.count_floor = atof(optarg); if (cfg.count_floor < 0) { fprintf(stderr, "--count-floor must be >= 0.\n"); return 1; } break;
             case 1005: cfg.set_mode = 1; break;
+            case 1006: cfg.rsh_cache = optarg ? optarg : ""; break;
             default: usage(argv[0]); return 1;
         }
     }
@@ -236,8 +239,23 @@ int main(int argc, char **argv) {
     char err[512];
     emsar_rsh *rsh = NULL;
     double t0 = now_s();
-    int rc = emsar_rsh_read(cfg.rsh_path, &rsh, err, sizeof err);
+    int rc = -1, from_cache = 0;
+    char *cache_path = NULL;
+    if (cfg.rsh_cache) {                       /* <rsh>.bin next to the text unless a path was given */
+        size_t n = strlen(cfg.rsh_cache[0] ? cfg.rsh_cache : cfg.rsh_path) + 8;
+        cache_path = (char *)malloc(n);
+        if (!cache_path) { fprintf(stderr, "out of memory\n"); return 1; }
+        if (cfg.rsh_cache[0]) snprintf(cache_path, n, "%s", cfg.rsh_cache); else snprintf(cache_path, n, "%s.bin", cfg.rsh_path);
+        rc = emsar_rsh_read_cache(cfg.rsh_path, cache_path, &rsh, err, sizeof err);
+        if (rc == 0) from_cache = 1;
+        else if (cfg.verbose > 1) fprintf(stdout, "rsh cache not used (%s)\n", err);
+    }
+    if (rc) rc = emsar_rsh_read(cfg.rsh_path, &rsh, err, sizeof err);
     if (rc) { fprintf(stderr, "%s\n", err); return 1; }
+    if (cache_path && !from_cache && emsar_rsh_write_cache(rsh, cfg.rsh_path, cache_path) != 0)
+        fprintf(stderr, "warning: can't write the rsh cache %s\n", cache_path);
+    if (cfg.verbose > 0 && from_cache) fprintf(stdout, "rsh: binary cache %s\n", cache_path);
+    free(cache_path);
     if (cfg.verbose > 0) fprintf(stdout, "rsh: %d transcripts, %lld segments, fragment lengths %d-%d (%.2fs)\n", rsh->n_tx,
                                  (long long)rsh->n_rows, rsh->frag_min, rsh->frag_max, now_s() - t0);
 

@@ -47,6 +47,12 @@ typedef struct emsar_rsh {
 
 int  emsar_rsh_read(const char *path, emsar_rsh **out, char *err, size_t errlen);
 void emsar_rsh_free(emsar_rsh *r);
+/* binary cache of the parsed arrays (a human PE rsh is gigabytes of text): write after a text parse, read instead of
+ * one.  read_cache refuses a file that is not ours, is truncated or inconsistent, or -- when src_path is given -- was
+ * made from a text of another size / mtime; the caller then parses the text. */
+int  emsar_rsh_write_cache(const emsar_rsh *r, const char *src_path, const char *cache_path);
+int  emsar_rsh_read_cache(const char *src_path /* may be NULL: no staleness check */, const char *cache_path, emsar_rsh **out,
+                          char *err, size_t errlen);
 int32_t emsar_rsh_tid_of(const emsar_rsh *r, const char *name);                 /* -1 if unknown */
 int64_t emsar_rsh_row_of(const emsar_rsh *r, const int32_t *sorted_tids, int n); /* -1 if no such segment */
 

@@ -13,6 +13,9 @@
  */
 #include "emsar_host.h"
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -248,6 +251,114 @@ done:
     if (single) { for (int32_t t = 0; t < r->n_tx; t++) free(single[t]); free(single); }
     for (size_t i = 0; i < n_multi; i++) { free(multi[i].tids); free(multi[i].euma); }
     free(multi);
+    if (rc != EMSAR_HOST_OK) { emsar_rsh_free(r); return rc; }
+    *out = r;
+    return EMSAR_HOST_OK;
+}
+
+/* ---- binary cache of a parsed rsh ---------------------------------------------------------------
+ * A human paired-end rsh is 10^6+ text lines of up to 400 integers; the text is parsed once and the flat arrays are
+ * written next to it.  File = header, names (NUL-terminated, back to back), row_ptr, col_idx, euma, has_node; all
+ * native-endian, fixed-width.  The header carries the size and mtime of the text it was made from: a stale or
+ * foreign file is refused and the caller falls back to the text. */
+typedef struct {
+    char magic[8];                    /* "EMSARSH1" */
+    uint32_t version, endian;         /* 1, 0x01020304 */
+    int32_t n_tx, hdr_minfrag, hdr_maxfrag, hdr_readlength, max_t_size, frag_min, frag_max, nfl;
+    int64_t n_rows, nnz, names_bytes, src_size, src_mtime;
+} rsh_cache_header;
+
+static int src_stamp(const char *path, int64_t *size, int64_t *mtime) {
+    struct stat st;
+    if (stat(path, &st) != 0) return -1;
+    *size = (int64_t)st.st_size; *mtime = (int64_t)st.st_mtime;
+    return 0;
+}
+
+int emsar_rsh_write_cache(const emsar_rsh *r, const char *src_path, const char *cache_path) {
+    rsh_cache_header h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "EMSARSH1", 8);
+    h.version = 1; h.endian = 0x01020304u;
+    h.n_tx = r->n_tx; h.hdr_minfrag = r->hdr_minfrag; h.hdr_maxfrag = r->hdr_maxfrag; h.hdr_readlength = r->hdr_readlength;
+    h.max_t_size = r->max_t_size; h.frag_min = r->frag_min; h.frag_max = r->frag_max; h.nfl = r->nfl;
+    h.n_rows = r->n_rows; h.nnz = (int64_t)r->row_ptr[r->n_rows];
+    for (int32_t t = 0; t < r->n_tx; t++) h.names_bytes += (int64_t)strlen(r->names[t]) + 1;
+    if (src_stamp(src_path, &h.src_size, &h.src_mtime)) return EMSAR_HOST_ERR_IO;
+    size_t plen = strlen(cache_path);
+    char *tmp = (char *)malloc(plen + 16);
+    if (!tmp) return EMSAR_HOST_ERR_OOM;
+    snprintf(tmp, plen + 16, "%s.tmp%d", cache_path, (int)getpid());
+    FILE *f = fopen(tmp, "wb");
+    int ok = f != NULL;
+    if (ok) ok = fwrite(&h, sizeof h, 1, f) == 1;
+    for (int32_t t = 0; ok && t < r->n_tx; t++) { size_t n = strlen(r->names[t]) + 1; ok = fwrite(r->names[t], 1, n, f) == n; }
+    if (ok) ok = fwrite(r->row_ptr, sizeof(uint64_t), (size_t)r->n_rows + 1, f) == (size_t)r->n_rows + 1;
+    if (ok && h.nnz) ok = fwrite(r->col_idx, sizeof(int32_t), (size_t)h.nnz, f) == (size_t)h.nnz;
+    size_t ne = (size_t)r->n_rows * (size_t)r->nfl;
+    if (ok && ne) ok = fwrite(r->euma, sizeof(int32_t), ne, f) == ne;
+    if (ok && r->n_rows) ok = fwrite(r->has_node, 1, (size_t)r->n_rows, f) == (size_t)r->n_rows;
+    if (f && fclose(f) != 0) ok = 0;
+    if (ok && rename(tmp, cache_path) != 0) ok = 0;      /* readers never see a half-written file */
+    if (!ok) remove(tmp);
+    free(tmp);
+    return ok ? EMSAR_HOST_OK : EMSAR_HOST_ERR_IO;
+}
+
+int emsar_rsh_read_cache(const char *src_path, const char *cache_path, emsar_rsh **out, char *err, size_t errlen) {
+    *out = NULL;
+    int rc = EMSAR_HOST_OK;
+    char *blob = NULL;
+    emsar_rsh *r = NULL;
+    FILE *f = fopen(cache_path, "rb");
+    if (!f) { if (err) snprintf(err, errlen, "can't open %s", cache_path); return EMSAR_HOST_ERR_IO; }
+#define CFAIL(code, msg) do { rc = (code); if (err) snprintf(err, errlen, "%s: %s", cache_path, (msg)); goto done; } while (0)
+    rsh_cache_header h;
+    if (fread(&h, sizeof h, 1, f) != 1) CFAIL(EMSAR_HOST_ERR_FORMAT, "short header");
+    if (memcmp(h.magic, "EMSARSH1", 8) != 0 || h.version != 1 || h.endian != 0x01020304u) CFAIL(EMSAR_HOST_ERR_FORMAT, "not an emsar rsh cache of this version");
+    int64_t ssz = 0, smt = 0;
+    if (src_path && (src_stamp(src_path, &ssz, &smt) || ssz != h.src_size || smt != h.src_mtime)) CFAIL(EMSAR_HOST_ERR_FORMAT, "stale: the rsh text has changed");
+    if (h.n_tx <= 0 || h.n_rows < h.n_tx || h.nnz < 0 || h.nfl <= 0 || h.nfl != h.frag_max - h.frag_min + 1 || h.names_bytes < h.n_tx)
+        CFAIL(EMSAR_HOST_ERR_FORMAT, "inconsistent header");
+    r = (emsar_rsh *)calloc(1, sizeof(*r));
+    if (!r) CFAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+    r->n_tx = h.n_tx; r->hdr_minfrag = h.hdr_minfrag; r->hdr_maxfrag = h.hdr_maxfrag; r->hdr_readlength = h.hdr_readlength;
+    r->max_t_size = h.max_t_size; r->frag_min = h.frag_min; r->frag_max = h.frag_max; r->nfl = h.nfl; r->n_rows = h.n_rows;
+    blob = (char *)malloc((size_t)h.names_bytes);
+    r->names = (char **)calloc((size_t)h.n_tx, sizeof(char *));
+    r->row_ptr = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)h.n_rows + 1));
+    r->col_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(h.nnz ? h.nnz : 1));
+    size_t ne = (size_t)h.n_rows * (size_t)h.nfl;
+    r->euma = (int32_t *)malloc(sizeof(int32_t) * (ne ? ne : 1));
+    r->has_node = (uint8_t *)malloc((size_t)h.n_rows);
+    if (!blob || !r->names || !r->row_ptr || !r->col_idx || !r->euma || !r->has_node) CFAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+    if (fread(blob, 1, (size_t)h.names_bytes, f) != (size_t)h.names_bytes || blob[h.names_bytes - 1] != 0) CFAIL(EMSAR_HOST_ERR_FORMAT, "truncated names");
+    {
+        const char *q = blob, *end = blob + h.names_bytes;
+        for (int32_t t = 0; t < h.n_tx; t++) {
+            if (q >= end) CFAIL(EMSAR_HOST_ERR_FORMAT, "fewer names than transcripts");
+            size_t n = strlen(q);
+            r->names[t] = (char *)malloc(n + 1);
+            if (!r->names[t]) CFAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+            memcpy(r->names[t], q, n + 1);
+            q += n + 1;
+        }
+    }
+    if (fread(r->row_ptr, sizeof(uint64_t), (size_t)h.n_rows + 1, f) != (size_t)h.n_rows + 1) CFAIL(EMSAR_HOST_ERR_FORMAT, "truncated row_ptr");
+    if (h.nnz && fread(r->col_idx, sizeof(int32_t), (size_t)h.nnz, f) != (size_t)h.nnz) CFAIL(EMSAR_HOST_ERR_FORMAT, "truncated col_idx");
+    if (ne && fread(r->euma, sizeof(int32_t), ne, f) != ne) CFAIL(EMSAR_HOST_ERR_FORMAT, "truncated euma");
+    if (fread(r->has_node, 1, (size_t)h.n_rows, f) != (size_t)h.n_rows) CFAIL(EMSAR_HOST_ERR_FORMAT, "truncated has_node");
+    /* the arrays index each other: check before anything walks them */
+    if (r->row_ptr[0] != 0 || r->row_ptr[h.n_rows] != (uint64_t)h.nnz) CFAIL(EMSAR_HOST_ERR_FORMAT, "row_ptr does not span col_idx");
+    for (int64_t c = 0; c < h.n_rows; c++) if (r->row_ptr[c + 1] < r->row_ptr[c]) CFAIL(EMSAR_HOST_ERR_FORMAT, "row_ptr not monotone");
+    for (int64_t k = 0; k < h.nnz; k++) if (r->col_idx[k] < 0 || r->col_idx[k] >= h.n_tx) CFAIL(EMSAR_HOST_ERR_FORMAT, "tid out of range");
+    r->name_index = ni_build(r->names, r->n_tx);
+    r->set_index = si_build(r);
+    if (!r->name_index || !r->set_index) CFAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+#undef CFAIL
+done:
+    fclose(f);
+    free(blob);
     if (rc != EMSAR_HOST_OK) { emsar_rsh_free(r); return rc; }
     *out = r;
     return EMSAR_HOST_OK;

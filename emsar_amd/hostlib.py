@@ -61,6 +61,8 @@ def lib():
         L.emsar_counts_free.restype = None
         L.emsar_model_build.argtypes = [C.POINTER(Rsh), C.POINTER(Counts), C.c_int, C.POINTER(C.c_double),
                                         C.POINTER(C.POINTER(Model)), C.c_char_p, C.c_size_t]
+        L.emsar_rsh_write_cache.argtypes = [C.POINTER(Rsh), C.c_char_p, C.c_char_p]
+        L.emsar_rsh_read_cache.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.POINTER(Rsh)), C.c_char_p, C.c_size_t]
         L.emsar_model_wf.argtypes = [C.POINTER(Rsh), C.POINTER(Counts), C.POINTER(C.c_double)]
         L.emsar_model_build_L.argtypes = [C.POINTER(Rsh), C.POINTER(Counts), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.POINTER(Model)), C.c_char_p, C.c_size_t]
@@ -87,12 +89,17 @@ def _dp(a):
 
 
 class HostRsh:
-    def __init__(self, path):
+    def __init__(self, path, cache=None, check_source=True):
+        """cache = path of a binary cache to read INSTEAD of the text (HostError if it is stale, foreign or damaged)."""
         p = C.POINTER(Rsh)()
         err = C.create_string_buffer(512)
-        rc = lib().emsar_rsh_read(path.encode(), C.byref(p), err, 512)
+        if cache is None:
+            rc = lib().emsar_rsh_read(path.encode(), C.byref(p), err, 512)
+        else:
+            rc = lib().emsar_rsh_read_cache(path.encode() if check_source else None, cache.encode(), C.byref(p), err, 512)
         if rc != 0:
             raise HostError("rsh_read rc=%d: %s" % (rc, err.value.decode()))
+        self.path = path
         self._p = p
         r = p.contents
         self.n_tx, self.n_rows, self.nfl = r.n_tx, r.n_rows, r.nfl
@@ -102,6 +109,11 @@ class HostRsh:
         self.col_idx = _np(r.col_idx, int(self.row_ptr[-1]), np.int32)
         self.euma = _np(r.euma, r.n_rows * r.nfl, np.int32).reshape(r.n_rows, r.nfl)
         self.has_node = _np(r.has_node, r.n_rows, np.uint8)
+
+    def write_cache(self, cache_path):
+        rc = lib().emsar_rsh_write_cache(self._p, self.path.encode(), cache_path.encode())
+        if rc != 0:
+            raise HostError("rsh_write_cache rc=%d" % rc)
 
     def tid_of(self, name):
         return lib().emsar_rsh_tid_of(self._p, name.encode())

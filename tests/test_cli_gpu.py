@@ -88,3 +88,22 @@ def test_cli_errors(tmp_path):
     assert r.returncode != 0 and b"invalid strand type" in r.stderr
     r = subprocess.run([CLI], capture_output=True)
     assert r.returncode != 0 and b"Usage" in r.stderr
+
+
+def test_rsh_cache_and_streaming_only_give_the_same_files(tmp_path):
+    """--rsh-cache: the first run parses the text and writes the binary cache, the second reads it; --streaming-only
+    solves the whole matrix with the streaming passes instead of set by set.  All three write the same numbers."""
+    fx = get_fixture("syn2k_se")
+    cache = str(tmp_path / "idx.bin")
+    outs = []
+    for tag, extra in (("a", ["--rsh-cache=" + cache]), ("b", ["--rsh-cache=" + cache]), ("c", ["--streaming-only"])):
+        d = tmp_path / tag
+        cmd = [CLI, "-g"] + extra + fx.meta["opts"] + ["-I", os.path.join(fx.dir, "index.rsh"), str(d), "out", _aln(fx)]
+        r = subprocess.run(cmd, check=True, timeout=300, capture_output=True, text=True)
+        outs.append(r.stdout)
+        _check_fpkm_file(fx, str(d / "out.0.fpkm"))
+    assert os.path.exists(cache) and "binary cache" not in outs[0] and "binary cache" in outs[1]
+    assert open(tmp_path / "a" / "out.0.fpkm").read() == open(tmp_path / "b" / "out.0.fpkm").read()      # resident sets: bit-reproducible
+    assert open(tmp_path / "a" / "out.0.segments").read() == open(tmp_path / "b" / "out.0.segments").read()
+    a, c = O.read_fpkm(str(tmp_path / "a" / "out.0.fpkm")), O.read_fpkm(str(tmp_path / "c" / "out.0.fpkm"))
+    assert np.abs(a["fpkm"] - c["fpkm"]).max() <= 1e-5 * np.abs(c["fpkm"]).max() + 2e-6
