@@ -1519,6 +1519,7 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
     free_structure(ctx);
     ctx->n_rows = n_rows; ctx->n_tx = n_tx; ctx->nnz = (int64_t)row_ptr[n_rows];
     ctx->ptr64 = (uint64_t)ctx->nnz >= (1ull << 32);
+    if (const char *e = getenv("EMSAR_HIP_FORCE_PTR64")) { if (atoi(e) != 0) ctx->ptr64 = true; }   // test hook: the 64-bit row_ptr kernels on small inputs
     if (layout == EMSAR_LAYOUT_AUTO) {
         layout = (n_rows < ((int64_t)1 << 32)) ? EMSAR_LAYOUT_TILED : EMSAR_LAYOUT_CSR;
         if (const char *e = getenv("EMSAR_HIP_LAYOUT")) { int v = atoi(e); if (v >= 1 && v <= 3 && (v == 1 || n_rows < ((int64_t)1 << 32))) layout = v; }

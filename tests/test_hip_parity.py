@@ -237,3 +237,23 @@ def test_full_size_properties_cfg2(dev):
         dev.run_passes(3)
         b = dev.get_theta()
         assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
+
+
+def test_csr_with_64bit_row_pointers(monkeypatch):
+    """Config 5 at full size has nnz = 4e9, just under 2^32; above it the CSR kernels read 64-bit row pointers.  The
+    test hook forces that code path on a small matrix: same pass, same solve."""
+    s = synth.make_config("cfg5", 0.0005)
+    m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
+    want, _ = m.em_step(np.ones(s["n_tx"]), s["den"], n_threads=4)
+    monkeypatch.setenv("EMSAR_HIP_FORCE_PTR64", "1")
+    ctx = EmsarHip(0)
+    try:
+        ctx.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_CSR)
+        ctx.upload_sample(None, None, s["den"])
+        ctx.run_passes(1)
+        got = ctx.get_theta()
+        assert np.all(np.abs(got - want) <= 1e-11 * np.abs(want) + 1e-300)
+        info = ctx.info()
+        assert info["bytes_per_pass"] == 4 * len(s["col_idx"]) + 8 * (s["n_reads"] + 1) + 32 * s["n_tx"]      # P = 8
+    finally:
+        ctx.close()
