@@ -12,7 +12,7 @@
 //                     column-major 64-row slices (256 contiguous bytes per wave load)
 //   k_pass_csr        generic fallback on the caller's CSR, one lane per row, FP64 atomics to L2/HBM
 //   k_update          theta' = theta*acc/den, clears acc, max-relative-change reduction
-//   k_sq_*            SQUAREM extrapolation / acceptance entirely on the device (no host round trip)
+//   k_update_p2/p3, k_sq_extrap_ll   SQUAREM extrapolation / acceptance entirely on the device (no host round trip)
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -785,7 +785,8 @@ __global__ void k_fill_start(int n, const double *__restrict__ den, double *__re
 __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
                                                 const double *__restrict__ den, const double *__restrict__ u /* folded single-tid rows, may be null */,
                                                 double *__restrict__ th_out, double abs_floor, double count_floor, Scal *scal,
-                                                const uint8_t *__restrict__ kind /* non-null: only KIND_STREAMED transcripts enter the stopping rule */) {
+                                                const uint8_t *__restrict__ kind /* non-null: only KIND_STREAMED transcripts enter the stopping rule */,
+                                                int to_delta1 /* the first (plain) step of a SQUAREM cycle: the cycle's stopping rule */) {
     __shared__ double red[4];
     double d = 0.0;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
@@ -806,47 +807,60 @@ __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         d = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-        if (d > 0.0) atomicMax(&scal->delta_bits, (unsigned long long)__double_as_longlong(d));
+        if (d > 0.0) atomicMax(to_delta1 ? &scal->delta1_bits : &scal->delta_bits, (unsigned long long)__double_as_longlong(d));
     }
 }
 
 __global__ void k_cycle_begin(Scal *s) {
     s->ll[0] = s->ll[1] = s->ll[2] = s->ll[3] = 0.0;
     s->sr2 = s->sv2 = s->pen1 = s->penx = 0.0;
-    s->delta_bits = 0ull;
+    s->delta_bits = 0ull; s->delta1_bits = 0ull;
 }
 __global__ void k_scal_init(Scal *s) {
     s->stepmax = 1.0; s->s_used = 1.0; s->accepted = 0; s->rejected = 0; s->sum_a = s->sum_b = 0.0;
 }
 
-// after pass 1 and 2: r = th1-th0, v = (th2-th1)-r ; sr2=|r|^2, sv2=|v|^2, pen1 = sum th1*den
-__global__ __launch_bounds__(256) void k_sq_norms(int n, const double *__restrict__ th0, const double *__restrict__ th1,
-                                                  const double *__restrict__ th2, const double *__restrict__ den, Scal *scal) {
+// ---- the SQUAREM cycle of the streaming solve with the O(T) work folded into the three update kernels ----
+// (8 launches per cycle instead of 13: on a problem of a few thousand rows the cycle is pure launch latency)
+//   k_update_p1   th1 = EM(th0); stopping rule of the cycle -> delta1_bits
+//   k_update_p2   th2 = EM(th1); F(th1) terms: sum u log th1 -> ll[1], sum th1*den -> pen1; |r|^2, |v|^2
+//   k_sq_extrap_ll thx = th0 + 2 s r + s^2 v  (Varadhan & Roland 2008, S3: s = |r|/|v| clamped to [1, stepmax]); components that
+//                 would leave the interior keep the plain EM value th2; s <= 1.01 -> thx = th2; + sum u log thx -> ll[2]
+//   k_update_p3   th0 = accepted ? EM(thx) : th2, accepted iff F(thx) >= F(th1), F = ll - sum theta*den; step bounds x4 / :4
+__device__ __forceinline__ double em_new_theta(double x, double a, double dn, const double *u, int t) {
+    return dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
+}
+__global__ __launch_bounds__(256) void k_update_p2(int n, const double *__restrict__ th0, const double *__restrict__ th1, double *__restrict__ acc,
+                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th2, Scal *scal) {
     __shared__ double red[4];
-    int t = blockIdx.x * 256 + threadIdx.x;
-    double r2 = 0, v2 = 0, p1 = 0;
-    if (t < n) {
-        double r = th1[t] - th0[t], v = (th2[t] - th1[t]) - r;
-        r2 = r * r; v2 = v * v; p1 = th1[t] * den[t];
+    double r2 = 0, v2 = 0, p1 = 0, l1 = 0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+        const double x = th1[t], dn = den[t];
+        const double y = em_new_theta(x, acc[t], dn, u, t);
+        th2[t] = y;
+        acc[t] = 0.0;
+        const double r = x - th0[t], v = (y - x) - r;
+        r2 += r * r; v2 += v * v; p1 += x * dn;
+        if (u) { const double c = u[t]; if (c > 0.0 && x > 0.0) l1 += c * log(x); }
     }
     double a = block_sum<256>(r2, red); __syncthreads();
     double b = block_sum<256>(v2, red); __syncthreads();
-    double c = block_sum<256>(p1, red);
-    if (threadIdx.x == 0) { atomic_add_f64(&scal->sr2, a); atomic_add_f64(&scal->sv2, b); atomic_add_f64(&scal->pen1, c); }
+    double c = block_sum<256>(p1, red); __syncthreads();
+    double d = block_sum<256>(l1, red);
+    if (threadIdx.x == 0) {
+        atomic_add_f64(&scal->sr2, a); atomic_add_f64(&scal->sv2, b); atomic_add_f64(&scal->pen1, c);
+        if (d != 0.0) atomic_add_f64(&scal->ll[1], d);
+    }
 }
-
-// thx = th0 + 2 s r + s^2 v  (Varadhan & Roland 2008, S3: s = |r|/|v| clamped to [1, stepmax]); components that
-// would leave the interior keep the plain EM value th2; s <= 1.01 -> thx = th2 (pass 3 is then one more EM step)
-__global__ __launch_bounds__(256) void k_sq_extrap(int n, const double *__restrict__ th0, const double *__restrict__ th1,
-                                                   const double *__restrict__ th2, const double *__restrict__ den,
-                                                   double *__restrict__ thx, Scal *scal) {
+__global__ __launch_bounds__(256) void k_sq_extrap_ll(int n, const double *__restrict__ th0, const double *__restrict__ th1,
+                                                      const double *__restrict__ th2, const double *__restrict__ den, const double *__restrict__ u,
+                                                      double *__restrict__ thx, Scal *scal) {
     __shared__ double red[4];
     double s = scal->sv2 > 0.0 ? sqrt(scal->sr2 / scal->sv2) : 1.0;
     s = fmin(fmax(s, 1.0), scal->stepmax);
     const bool extrap = s > 1.01;
-    int t = blockIdx.x * 256 + threadIdx.x;
-    double px = 0;
-    if (t < n) {
+    double px = 0, lx = 0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
         double x2 = th2[t], x = x2;
         if (extrap) {
             double r = th1[t] - th0[t], v = (x2 - th1[t]) - r;
@@ -854,24 +868,28 @@ __global__ __launch_bounds__(256) void k_sq_extrap(int n, const double *__restri
             x = (y > 0.0 && x2 > 0.0) ? y : x2;
         }
         thx[t] = x;
-        px = x * den[t];
+        px += x * den[t];
+        if (u) { const double c = u[t]; if (c > 0.0 && x > 0.0) lx += c * log(x); }
     }
-    double p = block_sum<256>(px, red);
+    double p = block_sum<256>(px, red); __syncthreads();
+    double l = block_sum<256>(lx, red);
     if (threadIdx.x == 0) {
         atomic_add_f64(&scal->penx, p);
+        if (l != 0.0) atomic_add_f64(&scal->ll[2], l);
         if (blockIdx.x == 0) scal->s_used = extrap ? s : 1.0;
     }
 }
-
-// after pass 3 (thn = EM(thx), ll[2] = sum R log S at thx): accept iff F(thx) >= F(th1), F = ll - sum theta*den
-__global__ __launch_bounds__(256) void k_sq_accept(int n, const double *__restrict__ thn, const double *__restrict__ th2,
-                                                   double *__restrict__ th0, Scal *scal) {
+__global__ __launch_bounds__(256) void k_update_p3(int n, const double *__restrict__ thx, const double *__restrict__ th2, double *__restrict__ acc,
+                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th0, Scal *scal) {
     const double s = scal->s_used;
     const bool extrap = s > 1.0;
     const bool ok = !extrap || (scal->ll[2] - scal->penx >= scal->ll[1] - scal->pen1);
-    int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < n) th0[t] = ok ? thn[t] : th2[t];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+        const double y = em_new_theta(thx[t], acc[t], den[t], u, t);
+        acc[t] = 0.0;
+        th0[t] = ok ? y : th2[t];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // nobody reads these three during this kernel
         double sm = scal->stepmax;
         if (!ok) { scal->rejected++; if (s >= sm) sm = fmax(1.0, sm / 4.0); }
         else { scal->accepted++; }
@@ -1265,7 +1283,7 @@ void free_structure(emsar_hip_ctx *ctx) {
 }
 
 // one pass of the chosen layout.  mode: MODE_EM / MODE_EM_LL / MODE_SCATTER
-int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, double *ll_out) {
+int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, double *ll_out, bool rows_only = false /* the folded rows' likelihood terms are added by the caller */) {
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
         const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
         if (ctx->n_tiles > 0) {
@@ -1299,7 +1317,7 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
             else { if (mode == MODE_EM_LL) LAUNCH_L(false, MODE_EM_LL); else LAUNCH_L(false, MODE_EM); }
 #undef LAUNCH_L
         }
-        if (mode == MODE_EM_LL)
+        if (mode == MODE_EM_LL && !rows_only)
             hipLaunchKernelGGL(k_single_ll, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx,
                                ctx->d_u, theta, ll_out);
         HIPCHK(hipGetLastError());
@@ -1336,12 +1354,12 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
 }
 
 // th_out = EM(th_in); ll slot receives sum R log S at th_in when want_ll
-int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_ll, int ll_slot, double abs_floor) {
+int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_ll, int ll_slot, double abs_floor, int to_delta1 = 0) {
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot]);
     if (rc) return rc;
     hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
                        ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->d_scal,
-                       ctx->delta_mask);
+                       ctx->delta_mask, to_delta1);
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
 }
@@ -1796,14 +1814,15 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
             std::swap(th[0], th[1]);
             iters += 1;
         } else {
-            // delta is measured on the first (plain) step of the cycle only: pass 2/3 must not overwrite it
-            if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor))) return rc;
-            HIPCHK(hipMemcpyAsync(&ctx->d_scal->delta1_bits, &ctx->d_scal->delta_bits, 8, hipMemcpyDeviceToDevice, ctx->stream));
-            if ((rc = em_pass(ctx, th[1], th[2], true, 1, p.abs_floor))) return rc;
-            hipLaunchKernelGGL(k_sq_norms, dim3(g), dim3(256), 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, ctx->d_scal);
-            hipLaunchKernelGGL(k_sq_extrap, dim3(g), dim3(256), 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, th[3], ctx->d_scal);
-            if ((rc = em_pass(ctx, th[3], th[4], true, 2, p.abs_floor))) return rc;
-            hipLaunchKernelGGL(k_sq_accept, dim3(g), dim3(256), 0, ctx->stream, n, th[4], th[2], th[0], ctx->d_scal);
+            // the stopping rule is measured on the first (plain) step of the cycle only (delta1_bits)
+            const double *u = ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr;
+            const dim3 gv((unsigned)std::min(g, 256)), bv(256);
+            if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor, 1))) return rc;
+            if ((rc = launch_pass(ctx, MODE_EM_LL, th[1], ctx->d_acc, &ctx->d_scal->ll[1], true))) return rc;
+            hipLaunchKernelGGL(k_update_p2, gv, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal);
+            hipLaunchKernelGGL(k_sq_extrap_ll, gv, bv, 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, u, th[3], ctx->d_scal);
+            if ((rc = launch_pass(ctx, MODE_EM_LL, th[3], ctx->d_acc, &ctx->d_scal->ll[2], true))) return rc;
+            hipLaunchKernelGGL(k_update_p3, gv, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal);
             HIPCHK(hipGetLastError());
             iters += 3;
         }
