@@ -1794,8 +1794,9 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     ctx->delta_mask = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
     int rc;
-    const bool use_sets = p.set_mode == 0;
+    bool use_sets = p.set_mode == 0;
     if (use_sets && (rc = ensure_sets(ctx))) return rc;
+    if (use_sets && ctx->RS.giant) use_sets = false;      // one component holds most transcripts: plain streaming solve
     // the streaming passes run when asked for, or for the sets that do not fit a workgroup
     const bool need_stream = !use_sets || ctx->RS.n_streamed_sets > 0;
     if (use_sets && need_stream) ctx->delta_mask = ctx->d_kind;
@@ -1879,6 +1880,7 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
         stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         stats->bytes_per_pass = ctx->bytes_formula;
         stats->stored_bytes_per_pass = stored_bytes(ctx);
+        if (p.set_mode == 0 && ctx->RS.giant) { stats->sets_streamed = 1; stats->sets_build_ms = ctx->sets_build_ms; }
         if (use_sets) {
             stats->sets_resident = (int32_t)ctx->RS.n_resident();
             stats->sets_streamed = (int32_t)ctx->RS.n_streamed_sets;

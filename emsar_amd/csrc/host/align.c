@@ -33,14 +33,22 @@ typedef struct { char qname[1024]; char rname[1024]; char md[4096]; int flag, po
 
 /* ---- BAM: BGZF is a series of gzip members, which zlib's gzread() inflates transparently (SAM/BAM spec section 4).
  * The reference reads BAM through its vendored samtools 0.1.19 (bam.c, bgzf.c); only the fields above are used. ---- */
-typedef struct { gzFile f; int n_ref; char **ref; unsigned char *buf; size_t cap; } bamreader;
+typedef struct { gzFile f; struct emsar_pbgzf *pf; int n_ref; char **ref; unsigned char *buf; size_t cap; } bamreader;
 
-static int bam_rd(bamreader *b, void *dst, size_t n) { return gzread(b->f, dst, (unsigned)n) == (int)n ? 0 : -1; }
+/* bytes delivered (short only at the end of the stream), -1 on error: the BGZF blocks of a regular file are inflated
+ * by a pool of threads (pbgzf.c), anything else (stdin, plain gzip) by zlib on this thread */
+static long bam_get(bamreader *b, void *dst, size_t n) {
+    if (b->pf) return emsar_pbgzf_read(b->pf, dst, n);
+    int got = gzread(b->f, dst, (unsigned)n);
+    return got < 0 ? -1 : (long)got;
+}
+static int bam_rd(bamreader *b, void *dst, size_t n) { return bam_get(b, dst, n) == (long)n ? 0 : -1; }
 static int32_t le32(const unsigned char *p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 
 static void bam_close(bamreader *b) {
     if (!b) return;
     if (b->f) gzclose(b->f);
+    emsar_pbgzf_close(b->pf);
     if (b->ref) { for (int i = 0; i < b->n_ref; i++) free(b->ref[i]); free(b->ref); }
     free(b->buf); free(b);
 }
@@ -48,9 +56,10 @@ static void bam_close(bamreader *b) {
 static bamreader *bam_open(const char *path) {
     bamreader *b = (bamreader *)calloc(1, sizeof(*b));
     if (!b) return NULL;
-    b->f = (path && path[0] && strcmp(path, "-") != 0) ? gzopen(path, "rb") : gzdopen(0, "rb");
+    b->pf = emsar_pbgzf_open(path);
+    if (!b->pf) b->f = (path && path[0] && strcmp(path, "-") != 0) ? gzopen(path, "rb") : gzdopen(0, "rb");
     unsigned char h[8];
-    if (!b->f || bam_rd(b, h, 8) || memcmp(h, "BAM\1", 4) != 0) { bam_close(b); return NULL; }
+    if ((!b->f && !b->pf) || bam_rd(b, h, 8) || memcmp(h, "BAM\1", 4) != 0) { bam_close(b); return NULL; }
     int32_t l_text = le32(h + 4);
     if (l_text < 0) { bam_close(b); return NULL; }
     for (int32_t i = 0; i < l_text; i++) { unsigned char c; if (bam_rd(b, &c, 1)) { bam_close(b); return NULL; } }
@@ -73,7 +82,7 @@ static bamreader *bam_open(const char *path) {
 /* returns 1 record read, 0 end of file, -1 malformed */
 static int bam_next(bamreader *b, samrec *r) {
     unsigned char h[4];
-    int got = gzread(b->f, h, 4);
+    long got = bam_get(b, h, 4);
     if (got == 0) return 0;
     if (got != 4) return -1;
     int32_t bs = le32(h);

@@ -56,6 +56,13 @@ int  emsar_rsh_read_cache(const char *src_path /* may be NULL: no staleness chec
 int32_t emsar_rsh_tid_of(const emsar_rsh *r, const char *name);                 /* -1 if unknown */
 int64_t emsar_rsh_row_of(const emsar_rsh *r, const int32_t *sorted_tids, int n); /* -1 if no such segment */
 
+/* parallel BGZF inflate (pbgzf.c): NULL from open = not a seekable BGZF file, use zlib's gzread instead.
+ * read returns the bytes delivered (< n only at the end of the file), -1 on a damaged block. */
+struct emsar_pbgzf;
+struct emsar_pbgzf *emsar_pbgzf_open(const char *path);
+long emsar_pbgzf_read(struct emsar_pbgzf *p, void *dst, size_t n);
+void emsar_pbgzf_close(struct emsar_pbgzf *p);
+
 typedef struct {
     int pe;              /* -P */
     char strand;         /* library_strand_type: 0, '+', '-'  (set_library_strand_type, emsar_functions.c:16-22) */

@@ -181,6 +181,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     // blocks stay small; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
     int32_t block = 512;
     if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 512) block = v; }
+    bool cut_at_slices = false;
+    if (const char *e = getenv("EMSAR_HIP_TILE_CUT")) cut_at_slices = atoi(e) != 0;
     // ---- sort: pass A by min tid, pass B by (block, length class); both stable ----
     std::vector<uint32_t> pa((size_t)n_act), perm((size_t)n_act);
     {
@@ -229,6 +231,21 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             i1++;
         }
         if ((int64_t)distinct.size() > kTileDict) return -3;       // a single row with too many tids: excluded by kMaxRowLen
+        // a tile closed by the dictionary or entry cap in the middle of a slice would pad that slice with empty rows
+        // (forward bytes and gathers for nothing): give the rows of the started slice to the next tile instead
+        if (cut_at_slices && i1 < n_act && i1 - i0 > kTileSliceRows && (i1 - i0) % kTileSliceRows != 0) {
+            const int64_t keep = (i1 - i0) / kTileSliceRows * kTileSliceRows;
+            for (int32_t t : distinct) stamp[(size_t)t] = -1;
+            distinct.clear();
+            i1 = i0 + keep;
+            for (int64_t i = i0; i < i1; i++) {
+                uint32_t r = perm[(size_t)i];
+                for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+                    int32_t t = col_idx[k];
+                    if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
+                }
+            }
+        }
         // 2. dictionary: the contiguous tid range [distinct[a], distinct[c]] that covers the MOST of the tile's
         //    tids while (range length + tids outside it) still fits; the tids outside (cross-family hits on
         //    either side) go to the explicit far list.  slots(a,c) = n + (tids missing inside the range).

@@ -56,6 +56,7 @@ struct ResidentSets {
     int64_t n_components = 0;         // with at least two transcripts
     int64_t n_streamed_sets = 0, n_streamed_tids = 0, n_resident_tids = 0, n_closed_tids = 0;
     int64_t rows_in = 0, rows_stored = 0;   // multi-transcript rows with weight before / after merging
+    bool giant = false;               // one component holds most of the transcripts: nothing was packed, stream everything
     int64_t n_resident() const { return (int64_t)(desc[0].size() + desc[1].size() + desc[2].size()); }
 };
 
@@ -74,10 +75,20 @@ inline int build_sets(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, con
     const size_t T = (size_t)n_tx;
     out.kind.assign(T, KIND_CLOSED);
     out.usum.assign(T, 0.0);
-    std::vector<int32_t> parent(T);
+    std::vector<int32_t> parent(T), csize(T, 1);
     std::iota(parent.begin(), parent.end(), 0);
     std::vector<int64_t> multi_rows;   // rows with weight and >= 2 distinct transcripts
+    int32_t largest = 1;
     for (int64_t r = 0; r < n_rows; r++) {
+        // a read-level matrix with a few cross-family reads is ONE component: stop looking as soon as more than
+        // half of the transcripts hang together (checked every 2^20 rows) -- the streaming passes take it all
+        if ((r & 0xFFFFF) == 0xFFFFF && (int64_t)largest * 2 > (int64_t)n_tx && n_tx > 4096) {
+            out.giant = true;
+            std::fill(out.kind.begin(), out.kind.end(), (uint8_t)KIND_STREAMED);
+            std::fill(out.usum.begin(), out.usum.end(), 0.0);
+            out.n_components = 1; out.n_streamed_sets = 1; out.n_streamed_tids = (int64_t)T;
+            return 0;
+        }
         const int32_t x = wgt ? wgt[r] : 1;
         const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
         if (x <= 0 || b == e) continue;
@@ -89,7 +100,12 @@ inline int build_sets(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, con
         int32_t ra = detail::uf_find(parent, first);
         for (uint64_t k = b + 1; k < e; k++) {
             int32_t rb = detail::uf_find(parent, col_idx[k]);
-            if (rb != ra) { if (rb < ra) std::swap(ra, rb); parent[(size_t)rb] = ra; }
+            if (rb != ra) {
+                if (rb < ra) std::swap(ra, rb);
+                parent[(size_t)rb] = ra;
+                csize[(size_t)ra] += csize[(size_t)rb];
+                largest = std::max(largest, csize[(size_t)ra]);
+            }
         }
     }
     out.rows_in = (int64_t)multi_rows.size();
@@ -170,7 +186,9 @@ inline int build_sets(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, con
         }
         const size_t nr = rep.size();
         const size_t bytes = set_lds_bytes(nt, nr, nnz);
-        if (bytes > cap || nr > 65535 || nnz > 65535) {
+        const bool offsets_fit = out.ent.size() + nnz < 0xFFFFFFFFull && out.row_w.size() + nr < 0xFFFFFFFFull &&
+                                 out.g_tid.size() + nt < 0xFFFFFFFFull && out.rp.size() + nr + 1 < 0xFFFFFFFFull;
+        if (bytes > cap || nr > 65535 || nnz > 65535 || !offsets_fit) {
             for (size_t i = 0; i < nt; i++) local[(size_t)tids[tptr[c] + i]] = -1;
             stream();
             continue;
@@ -227,6 +245,10 @@ inline int check_sets(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, con
                       const ResidentSets &S) {
     const size_t T = (size_t)n_tx;
     if (S.kind.size() != T || S.usum.size() != T) return 1;
+    if (S.giant) {                     // nothing packed, everything streamed
+        for (size_t t = 0; t < T; t++) if (S.kind[t] != KIND_STREAMED) return 15;
+        return S.n_resident() == 0 ? 0 : 15;
+    }
     std::vector<int32_t> set_of(T, -1), loc(T, -1);
     std::vector<const SetDesc *> all;
     for (const auto &v : S.desc) for (const auto &d : v) all.push_back(&d);

@@ -1,0 +1,102 @@
+"""CPU: parallel BGZF inflate (emsar_amd/csrc/host/pbgzf.c) behind the BAM reader -- a multi-block BAM made from a
+golden bowtie fixture must give the read counts of the text, with any number of threads; damaged blocks are errors."""
+import gzip
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from emsar_amd import _build, hostlib as HL
+from tests.conftest import get_fixture
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden as G
+
+
+@pytest.fixture(scope="module")
+def bam_case(tmp_path_factory):
+    _build.build_host()
+    fx = get_fixture("syn2k_se")
+    d = tmp_path_factory.mktemp("pbgzf")
+    r = HL.HostRsh(os.path.join(fx.dir, "index.rsh"))
+    sam = str(d / "reads.sam")
+    with open(sam, "w") as f:
+        for n in r.names:
+            f.write("@SQ\tSN:%s\tLN:100000\n" % n)
+        for line in gzip.open(os.path.join(fx.dir, "reads.bowtie.gz"), "rt"):
+            q = line.rstrip("\n").split("\t")                     # bowtie: name strand ref pos seq qual n mm
+            f.write(G.sam_line(q[0], 0 if q[1] == "+" else 16, q[2], int(q[3]), len(q[4]), str(len(q[4]))))
+    bam = str(d / "reads.bam")
+    G.sam_to_bam(sam, bam)
+    assert os.path.getsize(bam) > 3 * 20000                       # several BGZF blocks
+    want = r.count(os.path.join(fx.dir, "reads.bowtie.gz"))
+    return r, bam, want, d
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "16"])
+def test_bam_counts_equal_text_counts(bam_case, threads, monkeypatch):
+    r, bam, want, _ = bam_case
+    monkeypatch.setenv("EMSAR_HOST_THREADS", threads)
+    got = r.count(bam, fmt=2)
+    np.testing.assert_array_equal(got.R, want.R)
+    np.testing.assert_array_equal(got.frag_counts, want.frag_counts)
+    assert got.total_reads == want.total_reads and got.stats == want.stats
+
+
+def test_damaged_blocks_are_errors(bam_case):
+    r, bam, _, d = bam_case
+    raw = bytearray(open(bam, "rb").read())
+    # flip a byte inside the deflate data of the second block: CRC / inflate failure
+    bsize = raw[16] | (raw[17] << 8)
+    bad = bytearray(raw)
+    bad[bsize + 1 + 40] ^= 0xFF
+    p = str(d / "crc.bam")
+    open(p, "wb").write(bytes(bad))
+    with pytest.raises(HL.HostError):
+        r.count(p, fmt=2)
+    # truncated in the middle of a block
+    p = str(d / "trunc.bam")
+    open(p, "wb").write(bytes(raw[: len(raw) // 2]))
+    with pytest.raises(HL.HostError):
+        r.count(p, fmt=2)
+
+
+def test_many_batches(tmp_path, monkeypatch):
+    """More than one batch of 512 blocks: the prefetched batch takes over where the first one ends."""
+    import struct
+    import zlib
+    _build.build_host()
+    lib = HL.lib()
+    import ctypes as C
+    lib.emsar_pbgzf_open.restype = C.c_void_p
+    lib.emsar_pbgzf_open.argtypes = [C.c_char_p]
+    lib.emsar_pbgzf_read.restype = C.c_long
+    lib.emsar_pbgzf_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.emsar_pbgzf_close.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(0)
+    payload = rng.integers(0, 7, size=1300 * 3000, dtype=np.uint8).tobytes()      # 1300 small blocks
+    path = str(tmp_path / "x.bgzf")
+    with open(path, "wb") as fo:
+        for i in range(0, len(payload), 3000):
+            chunk = payload[i:i + 3000]
+            c = zlib.compressobj(1, zlib.DEFLATED, -15)
+            data = c.compress(chunk) + c.flush()
+            fo.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(data) + 25) + data +
+                     struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        fo.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    for threads in ("1", "5"):
+        monkeypatch.setenv("EMSAR_HOST_THREADS", threads)
+        h = lib.emsar_pbgzf_open(path.encode())
+        assert h
+        out = bytearray()
+        buf = C.create_string_buffer(70001)
+        while True:
+            n = lib.emsar_pbgzf_read(h, buf, 70001)
+            assert n >= 0
+            out += buf.raw[:n]
+            if n < 70001:
+                break
+        lib.emsar_pbgzf_close(h)
+        assert bytes(out) == payload
+    assert lib.emsar_pbgzf_open(os.path.join(os.path.dirname(__file__), "golden", "syn2k_se", "reads.bowtie.gz").encode()) is None   # plain gzip

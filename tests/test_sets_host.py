@@ -50,3 +50,12 @@ def test_random_block_matrices(seed):
     d = sets_selfcheck(n_tx, rp, ci, w if seed % 2 else None)
     assert d["tids_closed"] + d["tids_resident"] + d["tids_streamed"] == n_tx
     assert d["n_components"] == sum(d["sets_resident"]) + d["sets_streamed"]
+
+
+def test_giant_component_is_detected_early():
+    # a read-level matrix whose cross-family reads tie everything together: the builder stops after ~1M rows and
+    # leaves the whole problem to the streaming passes
+    from emsar_amd import synth
+    s = synth.make_matrix(n_tx=6000, n_reads=1200000, law="human", xfam=0.02, seed=3)
+    d = sets_selfcheck(s["n_tx"], s["row_ptr"], s["col_idx"])
+    assert d["sets_streamed"] == 1 and d["tids_streamed"] == s["n_tx"] and sum(d["sets_resident"]) == 0
