@@ -47,11 +47,12 @@ def _run(cmd, cwd=None):
 
 def build_hip(force=False):
     src = os.path.join(CSRC, "emsar_hip.hip")
-    deps = [src, os.path.join(CSRC, "layout.hpp"), os.path.join(CSRC, "layout_tiled.hpp"), os.path.join(CSRC, "sets.hpp"), os.path.join(ROOT, "include", "emsar_hip.h")]
+    src2 = os.path.join(CSRC, "collapse.hip")
+    deps = [src, src2, os.path.join(CSRC, "internal.hpp"), os.path.join(CSRC, "layout.hpp"), os.path.join(CSRC, "layout_tiled.hpp"), os.path.join(CSRC, "sets.hpp"), os.path.join(ROOT, "include", "emsar_hip.h")]
     if force or _stale(HIP_SO, deps):
         os.makedirs(BUILD, exist_ok=True)
         # compile inside build/ so that -save-temps leaves the .s (register / LDS usage) there
-        _run([HIPCC] + HIP_FLAGS + ["-save-temps", "-o", HIP_SO, src], cwd=BUILD)
+        _run([HIPCC] + HIP_FLAGS + ["-save-temps", "-o", HIP_SO, src, src2], cwd=BUILD)
     return HIP_SO
 
 

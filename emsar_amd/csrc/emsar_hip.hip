@@ -28,6 +28,7 @@
 #include "layout.hpp"
 #include "layout_tiled.hpp"
 #include "sets.hpp"
+#include "internal.hpp"
 
 namespace {
 
@@ -1469,6 +1470,10 @@ int solve_resident_sets(emsar_hip_ctx *ctx, const SetSolveParams &P, double *the
 }
 
 }  // namespace
+
+hipStream_t emsar_internal_stream(emsar_hip_ctx *ctx) { return ctx->stream; }
+int emsar_internal_device(const emsar_hip_ctx *ctx) { return ctx->device; }
+void emsar_internal_set_error(emsar_hip_ctx *ctx, const char *call, const char *what) { ctx->err = std::string(call) + ": " + what; }
 
 // ==================================================================================================
 // C ABI

@@ -18,7 +18,7 @@ SYMBOLS = [
     "emsar_hip_upload_structure", "emsar_hip_upload_sample", "emsar_hip_solve",
     "emsar_hip_reset_theta", "emsar_hip_set_theta", "emsar_hip_get_theta", "emsar_hip_run_passes",
     "emsar_hip_ieuma", "emsar_hip_normalise", "emsar_hip_get_info", "emsar_hip_layout_selfcheck",
-    "emsar_hip_layout_selfcheck_tiled", "emsar_hip_sets_selfcheck", "emsar_hip_upload_euma", "emsar_hip_adj_euma",
+    "emsar_hip_layout_selfcheck_tiled", "emsar_hip_sets_selfcheck", "emsar_hip_upload_euma", "emsar_hip_adj_euma", "emsar_hip_collapse_rows",
 ]
 
 
@@ -40,6 +40,11 @@ class EmStats(C.Structure):
                 ("sets_resident", C.c_int32), ("sets_streamed", C.c_int32), ("set_passes_max", C.c_int32),
                 ("sets_unconverged", C.c_int32), ("set_passes_sum", C.c_int64), ("sets_build_ms", C.c_double),
                 ("sets_kernel_ms", C.c_double)]
+
+
+class CollapseStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("n_rows", C.c_int64), ("nnz", C.c_int64),
+                ("n_unique", C.c_int64), ("nnz_unique", C.c_int64), ("table_slots", C.c_int64), ("algorithmic_bytes", C.c_int64)]
 
 
 class SetsInfo(C.Structure):
@@ -86,6 +91,8 @@ def load_library():
     L.emsar_hip_get_info.argtypes = [vp, C.POINTER(Info)]
     L.emsar_hip_layout_selfcheck.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int32, C.c_int64, C.POINTER(Info)]
     L.emsar_hip_layout_selfcheck_tiled.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int, C.POINTER(Info)]
+    L.emsar_hip_collapse_rows.argtypes = [vp, C.c_int64, C.c_int32, u64p, i32p, i32p, C.POINTER(C.c_int64), u64p, i32p, i32p, i32p,
+                                          C.POINTER(CollapseStats)]
     L.emsar_hip_upload_euma.argtypes = [vp, i32p, C.c_int32]
     L.emsar_hip_adj_euma.argtypes = [vp, f64p, f64p]
     L.emsar_hip_sets_selfcheck.argtypes = [C.c_int64, C.c_int32, u64p, i32p, i32p, C.POINTER(SetsInfo)]
@@ -205,6 +212,25 @@ class EmsarHip:
         out = np.zeros(self.n_tx)
         self._chk(self._L.emsar_hip_solve(self._h, C.byref(p), _p(out, C.c_double), C.byref(st)), "solve")
         return out, st
+
+    def collapse_rows(self, n_tx, row_ptr, col_idx, row_weight=None, want_map=True):
+        """Read -> segment collapse on the device: rows with the same multiset of ids become one weighted row.
+        Returns (row_ptr, col_idx, weight, row_map, stats); unique rows in order of first occurrence, ids sorted."""
+        row_ptr, col_idx = _arr(row_ptr, np.uint64), _arr(col_idx, np.int32)
+        n_rows = len(row_ptr) - 1
+        w = None if row_weight is None else _arr(row_weight, np.int32)
+        rp_o = np.zeros(n_rows + 1, dtype=np.uint64)
+        ci_o = np.zeros(max(len(col_idx), 1), dtype=np.int32)
+        w_o = np.zeros(max(n_rows, 1), dtype=np.int32)
+        m_o = np.zeros(max(n_rows, 1), dtype=np.int32) if want_map else None
+        nu = C.c_int64(0)
+        st = CollapseStats()
+        self._chk(self._L.emsar_hip_collapse_rows(self._h, n_rows, n_tx, _p(row_ptr, C.c_uint64), _p(col_idx, C.c_int32),
+                                                  None if w is None else _p(w, C.c_int32), C.byref(nu), _p(rp_o, C.c_uint64),
+                                                  _p(ci_o, C.c_int32), _p(w_o, C.c_int32), None if m_o is None else _p(m_o, C.c_int32),
+                                                  C.byref(st)), "collapse_rows")
+        u = nu.value
+        return rp_o[:u + 1], ci_o[:int(rp_o[u])], w_o[:u], (None if m_o is None else m_o[:n_rows]), st
 
     def upload_euma(self, euma):
         """EUMA[n_rows][nfl] (int32, 0 where absent): once per rsh, after upload_structure."""

@@ -146,6 +146,23 @@ int emsar_hip_normalise(emsar_hip_ctx *ctx, const double *mean_fpkm, const doubl
 int emsar_hip_upload_euma(emsar_hip_ctx *ctx, const int32_t *euma /* n_rows * nfl */, int32_t nfl);
 int emsar_hip_adj_euma(emsar_hip_ctx *ctx, const double *wf /* nfl */, double *adj_euma_out /* n_rows */);
 
+/* ---- read -> segment collapse: the integer core of update_ReadCounts (emsar_functions.c:838-943) ----------------
+ * Rows with the same MULTISET of transcript ids (order inside a row does not matter, repeats do: SURVEY.md A2) become
+ * one row whose weight is the sum of its members' weights (row_weight NULL = 1 each; rows with weight 0 and empty
+ * rows vanish).  Output rows are numbered by first occurrence -- the order in which the reference meets the segments
+ * -- with their ids sorted ascending.  Exact: hash matches are confirmed by comparing the rows themselves.
+ * The caller provides the output arrays at worst-case size (row_ptr_out n_rows+1, col_idx_out nnz, weight_out n_rows,
+ * row_map_out n_rows or NULL: original row -> output row, -1 for vanished rows).  Error if a sum exceeds INT32_MAX. */
+typedef struct {
+    double  kernel_ms;          /* device time of the collapse kernels (HIP events), transfers excluded */
+    double  total_ms;           /* wall time of the call */
+    int64_t n_rows, nnz, n_unique, nnz_unique, table_slots;
+    int64_t algorithmic_bytes;  /* CSR read twice (hash, compare) + weights + the unique rows written */
+} emsar_hip_collapse_stats;
+int emsar_hip_collapse_rows(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
+                            const int32_t *row_weight, int64_t *n_unique_out, uint64_t *row_ptr_out, int32_t *col_idx_out,
+                            int32_t *weight_out, int32_t *row_map_out, emsar_hip_collapse_stats *stats);
+
 /* ---- introspection ------------------------------------------------------------------------------ */
 typedef struct {
     int64_t n_rows, nnz;

@@ -60,6 +60,8 @@ def lib():
         L.oracle_mle_pattern_search.restype = C.c_int64
         L.oracle_mle_pattern_search.argtypes = csr + [i32p, f64p, i32p, C.c_int32, C.c_double, C.c_double,
                                                       C.c_int32, C.c_int32, C.c_uint32, C.c_int32, f64p]
+        L.oracle_collapse_rows.restype = C.c_int64
+        L.oracle_collapse_rows.argtypes = [C.c_int64, u64p, i32p, i32p, u64p, i32p, C.POINTER(C.c_int64), i32p]
         L.oracle_fpkm_table.argtypes = [C.c_int32, C.c_int32, f64p, f64p, C.c_int64, f64p, f64p, f64p, i32p, f64p]
         _LIB = L
     return _LIB
@@ -132,6 +134,23 @@ class Csr:
                                                  _p(cs, C.c_int32), n_sets, eps, eps_step, max_niter, max_nloop,
                                                  seed, n_threads, _p(out, C.c_double))
         return out, sweeps
+
+
+def collapse_rows(row_ptr, col_idx, row_weight=None):
+    """Read -> segment collapse as update_ReadCounts does it: (row_ptr, col_idx, weight[int64], row_map)."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+    col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+    n = len(row_ptr) - 1
+    w = None if row_weight is None else np.ascontiguousarray(row_weight, dtype=np.int32)
+    rp_o = np.zeros(n + 1, dtype=np.uint64)
+    ci_o = np.zeros(max(len(col_idx), 1), dtype=np.int32)
+    w_o = np.zeros(max(n, 1), dtype=np.int64)
+    m_o = np.zeros(max(n, 1), dtype=np.int32)
+    u = lib().oracle_collapse_rows(n, _p(row_ptr, C.c_uint64), _p(col_idx, C.c_int32), None if w is None else _p(w, C.c_int32),
+                                   _p(rp_o, C.c_uint64), _p(ci_o, C.c_int32), _p(w_o, C.c_int64), _p(m_o, C.c_int32))
+    if u < 0:
+        raise MemoryError("oracle_collapse_rows")
+    return rp_o[:u + 1], ci_o[:int(rp_o[u])], w_o[:u], m_o[:n]
 
 
 def fpkm_table(rounds, ieuma, total_read_count):

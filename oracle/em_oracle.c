@@ -450,3 +450,76 @@ void oracle_fpkm_table(int32_t n_tx, int32_t n_round, const double *rounds, cons
         tpm[t] = mu * 1E6 / total;
     }
 }
+
+
+/* ---- read -> segment collapse (update_ReadCounts, emsar_functions.c:838-943) ---- */
+typedef struct { const uint64_t *rp; const int32_t *sorted; } collapse_ctx;
+static const collapse_ctx *g_cc;                      /* qsort has no context argument in C11 */
+static int collapse_cmp(const void *a, const void *b) {
+    int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    uint64_t lx = g_cc->rp[x + 1] - g_cc->rp[x], ly = g_cc->rp[y + 1] - g_cc->rp[y];
+    if (lx != ly) return lx < ly ? -1 : 1;
+    const int32_t *p = g_cc->sorted + g_cc->rp[x], *q = g_cc->sorted + g_cc->rp[y];
+    for (uint64_t k = 0; k < lx; k++) if (p[k] != q[k]) return p[k] < q[k] ? -1 : 1;
+    return x < y ? -1 : x > y;                         /* equal tuples: by row id, so the first occurrence leads */
+}
+static int cmp_i64(const void *a, const void *b) { int64_t x = *(const int64_t *)a, y = *(const int64_t *)b; return x < y ? -1 : x > y; }
+
+int64_t oracle_collapse_rows(int64_t n_rows, const uint64_t *row_ptr, const int32_t *col_idx, const int32_t *row_weight,
+                             uint64_t *row_ptr_out, int32_t *col_idx_out, int64_t *weight_out, int32_t *row_map_out) {
+    const uint64_t nnz = row_ptr[n_rows];
+    int32_t *sorted = (int32_t *)malloc(sizeof(int32_t) * (nnz ? nnz : 1));
+    int64_t *order = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_rows ? n_rows : 1));
+    int64_t *leader = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_rows ? n_rows : 1));   /* first occurrence of each row's tuple */
+    int64_t *firsts = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_rows ? n_rows : 1));
+    if (!sorted || !order || !leader || !firsts) { free(sorted); free(order); free(leader); free(firsts); return -1; }
+    int64_t n_act = 0;
+    for (int64_t r = 0; r < n_rows; r++) {
+        uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+        for (uint64_t k = b; k < e; k++) {              /* insertion with >= : the reference's own order of equal ids */
+            int32_t v = col_idx[k];
+            uint64_t j = k;
+            while (j > b && sorted[j - 1] > v) { sorted[j] = sorted[j - 1]; j--; }
+            sorted[j] = v;
+        }
+        leader[r] = -1;
+        if (e > b && (!row_weight || row_weight[r] > 0)) order[n_act++] = r;
+    }
+    collapse_ctx cc = {row_ptr, sorted};
+    g_cc = &cc;
+    qsort(order, (size_t)n_act, sizeof(int64_t), collapse_cmp);
+    int64_t n_seg = 0;
+    for (int64_t i = 0; i < n_act;) {
+        int64_t j = i + 1;
+        while (j < n_act) {
+            int64_t x = order[i], y = order[j];
+            uint64_t lx = row_ptr[x + 1] - row_ptr[x];
+            if (lx != row_ptr[y + 1] - row_ptr[y] || memcmp(sorted + row_ptr[x], sorted + row_ptr[y], lx * sizeof(int32_t)) != 0) break;
+            j++;
+        }
+        for (int64_t k = i; k < j; k++) leader[order[k]] = order[i];
+        firsts[n_seg++] = order[i];
+        i = j;
+    }
+    qsort(firsts, (size_t)n_seg, sizeof(int64_t), cmp_i64);             /* segments in order of first occurrence */
+    int64_t *seg_of_first = order;                                        /* reuse: row id -> segment id for leaders */
+    for (int64_t r = 0; r < n_rows; r++) seg_of_first[r] = -1;
+    uint64_t o = 0;
+    for (int64_t s = 0; s < n_seg; s++) {
+        int64_t r = firsts[s];
+        seg_of_first[r] = s;
+        row_ptr_out[s] = o;
+        uint64_t len = row_ptr[r + 1] - row_ptr[r];
+        memcpy(col_idx_out + o, sorted + row_ptr[r], len * sizeof(int32_t));
+        o += len;
+        weight_out[s] = 0;
+    }
+    row_ptr_out[n_seg] = o;
+    for (int64_t r = 0; r < n_rows; r++) {
+        int64_t s = leader[r] < 0 ? -1 : seg_of_first[leader[r]];
+        if (s >= 0) weight_out[s] += row_weight ? row_weight[r] : 1;
+        if (row_map_out) row_map_out[r] = (int32_t)s;
+    }
+    free(sorted); free(order); free(leader); free(firsts);
+    return n_seg;
+}

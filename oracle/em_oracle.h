@@ -84,6 +84,14 @@ void oracle_fpkm_table(int32_t n_tx, int32_t n_round, const double *rounds, cons
                        int64_t total_read_count, double *mean, double *sd, double *ireadcount,
                        int32_t *ireadcount_int, double *tpm);
 
+/* read -> segment collapse, the reference's update_ReadCounts (emsar_functions.c:838-943) on a flat read-level matrix:
+ * every row's ids are sorted (insertion with >=: repeats are kept, emsar_functions.c:889); rows with the same sorted
+ * tuple are one segment whose count is the sum of the members' weights (NULL = 1 each; weight 0 and empty rows are
+ * skipped); segments are numbered in the order in which they are first met.  Arrays at worst-case size; returns the
+ * number of segments, -1 if out of memory. */
+int64_t oracle_collapse_rows(int64_t n_rows, const uint64_t *row_ptr, const int32_t *col_idx, const int32_t *row_weight,
+                             uint64_t *row_ptr_out, int32_t *col_idx_out, int64_t *weight_out, int32_t *row_map_out);
+
 #ifdef __cplusplus
 }
 #endif

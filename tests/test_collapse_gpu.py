@@ -1,0 +1,89 @@
+"""GPU: read -> segment collapse on the device (emsar_hip_collapse_rows) against the oracle's restatement of
+update_ReadCounts (oracle_collapse_rows).  Integer work: every output array must be IDENTICAL."""
+import numpy as np
+import pytest
+
+import oracle as O
+from emsar_amd import EmsarHip, EmsarHipError, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    ctx = EmsarHip(0)
+    yield ctx
+    ctx.close()
+
+
+def _same(dev, n_tx, rp, ci, w=None):
+    want = O.collapse_rows(rp, ci, w)
+    got = dev.collapse_rows(n_tx, rp, ci, w)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_array_equal(got[2].astype(np.int64), want[2])
+    np.testing.assert_array_equal(got[3], want[3])
+    return got
+
+
+
+
+def test_toy_semantics(dev):
+    # rows: {3,1,2} {2,3,1} {1,2} {} {1,1,2} {2,1,1} {1,2,2} {7} {7} ; weights with a zero
+    rows = [[3, 1, 2], [2, 3, 1], [1, 2], [], [1, 1, 2], [2, 1, 1], [1, 2, 2], [7], [7]]
+    rp = np.zeros(len(rows) + 1, dtype=np.uint64)
+    rp[1:] = np.cumsum([len(r) for r in rows])
+    ci = np.array([t for r in rows for t in r], dtype=np.int32)
+    got = _same(dev, 8, rp, ci)
+    assert [list(got[1][int(got[0][i]):int(got[0][i + 1])]) for i in range(len(got[2]))] == [[1, 2, 3], [1, 2], [1, 1, 2], [1, 2, 2], [7]]
+    assert list(got[2]) == [2, 1, 2, 1, 2] and list(got[3]) == [0, 0, 1, -1, 2, 2, 3, 4, 4]
+    w = np.array([5, 0, 2, 9, 1, 1, 0, 3, 4], dtype=np.int32)
+    got = _same(dev, 8, rp, ci, w)
+    assert list(got[2]) == [5, 2, 2, 7] and list(got[3]) == [0, -1, 1, -1, 2, 2, -1, 3, 3]
+
+
+@pytest.mark.parametrize("name,scale", [("cfg2", 0.02), ("cfg3", 0.01), ("cfg5", 0.0005)])
+def test_synthetic_configs(dev, name, scale):
+    s = synth.make_config(name, scale)
+    got = _same(dev, s["n_tx"], s["row_ptr"], s["col_idx"])
+    assert got[2].sum() == s["n_reads"] and got[4].n_unique == len(got[2])
+    rng = np.random.default_rng(1)
+    w = rng.integers(0, 4, size=s["n_reads"]).astype(np.int32)
+    got = _same(dev, s["n_tx"], s["row_ptr"], s["col_idx"], w)
+    assert got[2].sum() == w.sum()
+
+
+def test_collapsed_matrix_gives_the_same_em(dev):
+    s = synth.make_matrix(n_tx=3000, n_reads=200000, law="human", xfam=0.02, seed=21)
+    rp, ci, w, _, st = dev.collapse_rows(s["n_tx"], s["row_ptr"], s["col_idx"])
+    assert st.n_unique < 0.5 * s["n_reads"]
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"])
+    dev.upload_sample(None, None, s["den"])
+    dev.run_passes(20)
+    a = dev.get_theta()
+    dev.upload_structure(s["n_tx"], rp, ci)
+    dev.upload_sample(w, None, s["den"])
+    dev.run_passes(20)
+    b = dev.get_theta()
+    assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
+
+
+def test_edge_cases_and_errors(dev):
+    e = np.zeros(1, dtype=np.uint64)
+    got = dev.collapse_rows(4, e, np.zeros(0, dtype=np.int32))
+    assert len(got[2]) == 0 and list(got[0]) == [0]
+    rp = np.array([0, 0, 0], dtype=np.uint64)                      # only empty rows
+    got = dev.collapse_rows(4, rp, np.zeros(0, dtype=np.int32))
+    assert len(got[2]) == 0 and list(got[3]) == [-1, -1]
+    # one long row next to many copies of it in another order, and 64-bit sums that do not fit the output
+    long_row = np.arange(90, dtype=np.int32)
+    rows = [long_row, long_row[::-1], np.roll(long_row, 7)]
+    rp = np.arange(0, 91 * 3, 90, dtype=np.uint64)[:4]
+    got = _same(dev, 100, rp, np.concatenate(rows).astype(np.int32))
+    assert list(got[2]) == [3]
+    with pytest.raises(EmsarHipError):
+        dev.collapse_rows(100, rp, np.concatenate(rows).astype(np.int32), np.array([2 ** 31 - 1, 5, 0], dtype=np.int32))
+    with pytest.raises(EmsarHipError):
+        dev.collapse_rows(100, rp, np.concatenate(rows).astype(np.int32), np.array([-1, 5, 0], dtype=np.int32))
+    with pytest.raises(EmsarHipError):
+        dev.collapse_rows(50, rp, np.concatenate(rows).astype(np.int32))       # tid out of range
