@@ -808,7 +808,10 @@ __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         d = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-        if (d > 0.0) atomicMax(to_delta1 ? &scal->delta1_bits : &scal->delta_bits, (unsigned long long)__double_as_longlong(d));
+        // the word only grows during a kernel: workgroups whose maximum is already covered skip the same-address atomic
+        unsigned long long *dst = to_delta1 ? &scal->delta1_bits : &scal->delta_bits;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
+        if (d > 0.0 && bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
     }
 }
 
@@ -1214,6 +1217,7 @@ struct emsar_hip_ctx {
     int64_t bytes_formula = 0, bytes_stored = 0;
     int64_t tl_fwd_slots = 0, tl_n_fslices = 0;
     double count_floor = 0.0;    // stopping-rule floor in reads for the current solve (emsar_em_params.count_floor)
+    int update_grid = 256;       // workgroups of k_update (EMSAR_HIP_UPDATE_GRID)
     int tiled_multi = 2;         // 2: two tiles per workgroup, software-pipelined (k_pass_tiled_multi); 0: one (k_pass_tiled)
     const uint8_t *delta_mask = nullptr;   // d_kind while the streaming solve runs next to resident sets
     // set-resident solver (sets.hpp): host copy of the CSR and of the sample's row weights, built lazily by solve
@@ -1358,7 +1362,7 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
 int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_ll, int ll_slot, double abs_floor, int to_delta1 = 0) {
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot]);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
+    hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), ctx->update_grid)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
                        ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->d_scal,
                        ctx->delta_mask, to_delta1);
     HIPCHK(hipGetLastError());
@@ -1582,6 +1586,7 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
             SETLDS_P(false, MODE_EM, 2); SETLDS_P(false, MODE_EM_LL, 2);
 #undef SETLDS_P
             { const char *pe = getenv("EMSAR_HIP_TILED_MULTI"); ctx->tiled_multi = pe ? atoi(pe) : 2; }
+            { const char *pe = getenv("EMSAR_HIP_UPDATE_GRID"); if (pe && atoi(pe) >= 1) ctx->update_grid = atoi(pe); }
         } else if (layout == EMSAR_LAYOUT_WINDOWED) {
             const char *wenv = getenv("EMSAR_HIP_WINDOW");
             int window = wenv ? atoi(wenv) : kDefaultWindow;
