@@ -1,11 +1,11 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r01b
+O=$R/gpurun_out/prof_r01c
 mkdir -p $O
 cd $R
 python -m pytest tests -x -q -m gpu > $O/gpu_suite.txt 2>&1; tail -2 $O/gpu_suite.txt
-python bench.py --steps 100 > $O/bench.json 2> $O/bench.err; cat $O/bench.json
+python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum -d $O/pmc_write -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/p2.log 2>&1
