@@ -196,6 +196,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     // blocks stay small; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
     int32_t block = 512;
     if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 900) block = v; }
+    int64_t tile_rows = kTileRows;
+    if (const char *e = getenv("EMSAR_HIP_TILE_ROWS")) { int v = atoi(e); if (v >= kTileSliceRows && v <= kTileRows) tile_rows = v / kTileSliceRows * kTileSliceRows; }
     bool cut_at_slices = true;
     if (const char *e = getenv("EMSAR_HIP_TILE_CUT")) cut_at_slices = atoi(e) != 0;
     // ---- sort: pass A by min tid, pass B by (block, length class); both stable ----
@@ -228,7 +230,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         // 1. how many rows fit: row cap, entry cap, distinct-tid cap
         distinct.clear();
         int64_t ents = 0, i1 = i0;
-        while (i1 < n_act && i1 - i0 < kTileRows) {
+        while (i1 < n_act && i1 - i0 < tile_rows) {
             uint32_t r = perm[(size_t)i1];
             uint64_t b = row_ptr[r], e = row_ptr[r + 1];
             if (i1 > i0 && ents + (int64_t)(e - b) > kTileEntries) break;
