@@ -5,7 +5,7 @@
 //
 //   * rows with ONE tid never reach the kernel: they are folded into a per-transcript count vector u
 //     (acc_t += u_t / theta_t is applied analytically in k_update);
-//   * rows with 2..kMaxRowLen tids are sorted by (block(min tid), length class, min tid) like the WINDOWED
+//   * rows with 2..kMaxRowLen tids are sorted by (block(anchor tid), length class, anchor tid), anchor = median tid, like the WINDOWED
 //     layout and cut into TILES of at most 3072 rows whose distinct tids fit a 959-entry chunk-local
 //     DICTIONARY: the contiguous range [lo, lo+near_n) that covers most of the tile's tids plus an explicit list
 //     of far tids.  Every stored operand is a 10-BIT id (dictionary slot < 1024, slice row < 1024), three to a dword;
@@ -200,7 +200,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     if (const char *e = getenv("EMSAR_HIP_TILE_ROWS")) { int v = atoi(e); if (v >= kTileSliceRows && v <= kTileRows) tile_rows = v / kTileSliceRows * kTileSliceRows; }
     bool cut_at_slices = true;
     if (const char *e = getenv("EMSAR_HIP_TILE_CUT")) cut_at_slices = atoi(e) != 0;
-    // ---- sort: pass A by min tid, pass B by (block, length class); both stable ----
+    // ---- sort: pass A by anchor tid, pass B by (block, length class); both stable ----
     std::vector<uint32_t> pa((size_t)n_act), perm((size_t)n_act);
     {
         std::vector<uint64_t> cnt((size_t)n_tx + 1, 0);
