@@ -2,13 +2,13 @@
 """Read -> segment collapse of a BASELINE-shaped read-level matrix: device (emsar_hip_collapse_rows) against the oracle's
 restatement of update_ReadCounts on one host core.  Prints the kernel time, the algorithmic bytes and the HBM rate.
 
-    python tools/collapse_bench.py [config] [scale]
+    python tests/perf/collapse_bench.py [config] [scale]
 """
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 import oracle as O

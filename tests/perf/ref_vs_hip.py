@@ -2,7 +2,7 @@
 """End-to-end drop-in comparison on one box: the compiled reference (oracle/_ref/emsar, CPU) against emsar-hip (GPU)
 on the same synthetic rsh + default-bowtie input.  Prints wall times of both programs and the FPKM agreement.
 
-    python tools/ref_vs_hip.py [n_tx] [n_reads] [threads] [largest_family]
+    python tests/perf/ref_vs_hip.py [n_tx] [n_reads] [threads] [largest_family]
 
 The reference binary is test infrastructure (built in the build container from /root/reference by oracle/Makefile and
 shipped as a binary); it is used here only as the thing to compare against.
@@ -13,7 +13,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import numpy as np
