@@ -29,11 +29,11 @@ void emsar_lr_close(void *h);
 
 /* One SAM/BAM alignment record reduced to what the reference reads from bam1_t (emsar_functions.c:391-469):
  * qname, flag, reference name, 0-based position, l_qseq and the MD:Z string. */
-typedef struct { char qname[1024]; char rname[1024]; char md[4096]; int flag, pos, l_seq, unaligned; } samrec;
+typedef struct { char qname[1024]; char rname[1024]; char md[4096]; int flag, pos, l_seq, unaligned; int32_t tid; /* >= 0: already resolved (BAM: per reference, once), -1: look rname up */ } samrec;
 
 /* ---- BAM: BGZF is a series of gzip members, which zlib's gzread() inflates transparently (SAM/BAM spec section 4).
  * The reference reads BAM through its vendored samtools 0.1.19 (bam.c, bgzf.c); only the fields above are used. ---- */
-typedef struct { gzFile f; struct emsar_pbgzf *pf; int n_ref; char **ref; unsigned char *buf; size_t cap; } bamreader;
+typedef struct { gzFile f; struct emsar_pbgzf *pf; int n_ref; char **ref; int32_t *ref_tid; const emsar_rsh *rsh; unsigned char *buf; size_t cap; } bamreader;
 
 /* bytes delivered (short only at the end of the stream), -1 on error: the BGZF blocks of a regular file are inflated
  * by a pool of threads (pbgzf.c), anything else (stdin, plain gzip) by zlib on this thread */
@@ -50,12 +50,13 @@ static void bam_close(bamreader *b) {
     if (b->f) gzclose(b->f);
     emsar_pbgzf_close(b->pf);
     if (b->ref) { for (int i = 0; i < b->n_ref; i++) free(b->ref[i]); free(b->ref); }
-    free(b->buf); free(b);
+    free(b->ref_tid); free(b->buf); free(b);
 }
 
-static bamreader *bam_open(const char *path) {
+static bamreader *bam_open(const char *path, const emsar_rsh *rsh) {
     bamreader *b = (bamreader *)calloc(1, sizeof(*b));
     if (!b) return NULL;
+    b->rsh = rsh;
     b->pf = emsar_pbgzf_open(path);
     if (!b->pf) b->f = (path && path[0] && strcmp(path, "-") != 0) ? gzopen(path, "rb") : gzdopen(0, "rb");
     unsigned char h[8];
@@ -67,7 +68,9 @@ static bamreader *bam_open(const char *path) {
     b->n_ref = le32(h);
     if (b->n_ref < 0 || b->n_ref > (1 << 28)) { bam_close(b); return NULL; }
     b->ref = (char **)calloc((size_t)b->n_ref + 1, sizeof(char *));
-    if (!b->ref) { bam_close(b); return NULL; }
+    b->ref_tid = (int32_t *)malloc(sizeof(int32_t) * ((size_t)b->n_ref + 1));
+    if (!b->ref || !b->ref_tid) { bam_close(b); return NULL; }
+    for (int i = 0; i < b->n_ref; i++) b->ref_tid[i] = -2;          /* not looked up yet */
     for (int i = 0; i < b->n_ref; i++) {
         if (bam_rd(b, h, 4)) { bam_close(b); return NULL; }
         int32_t ln = le32(h);
@@ -94,12 +97,24 @@ static int bam_next(bamreader *b, samrec *r) {
     int l_name = p[8], n_cig = p[12] | (p[13] << 8), flag = p[14] | (p[15] << 8);
     size_t off = 32;
     if (off + (size_t)l_name > (size_t)bs || l_name < 1 || l_seq < 0) return -1;
-    snprintf(r->qname, sizeof r->qname, "%s", (const char *)(p + off));
+    {
+        size_t nl = strnlen((const char *)(p + off), (size_t)l_name);
+        if (nl >= sizeof r->qname) nl = sizeof r->qname - 1;
+        memcpy(r->qname, p + off, nl); r->qname[nl] = 0;
+    }
     off += (size_t)l_name + 4u * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
     if (off > (size_t)bs) return -1;
     r->flag = flag; r->pos = pos; r->l_seq = l_seq; r->md[0] = 0;
     r->unaligned = refid < 0 || refid >= b->n_ref;
-    snprintf(r->rname, sizeof r->rname, "%s", r->unaligned ? "*" : b->ref[refid]);
+    r->tid = -1;
+    if (r->unaligned) { r->rname[0] = '*'; r->rname[1] = 0; }
+    else {
+        /* reference id -> transcript id once per reference instead of a name lookup per record */
+        if (b->rsh && b->ref_tid[refid] == -2) b->ref_tid[refid] = emsar_rsh_tid_of(b->rsh, b->ref[refid]);
+        r->tid = b->rsh ? b->ref_tid[refid] : -1;
+        if (r->tid < 0) snprintf(r->rname, sizeof r->rname, "%s", b->ref[refid]);      /* unknown: the caller reports the name */
+        else r->rname[0] = 0;
+    }
     while (off + 3 <= (size_t)bs) {                               /* auxiliary fields: find MD:Z */
         const unsigned char *a = p + off;
         char ty = (char)a[2];
@@ -140,6 +155,7 @@ static int sam_parse(char *line, samrec *r) {
     if (nf < 11) return -1;
     snprintf(r->qname, sizeof r->qname, "%s", f[0]);
     snprintf(r->rname, sizeof r->rname, "%s", f[2]);
+    r->tid = -1;
     r->flag = atoi(f[1]); r->pos = atoi(f[3]) - 1; r->l_seq = (int)strlen(f[9]); r->md[0] = 0;
     r->unaligned = strcmp(f[2], "*") == 0;
     for (int i = 11; i < nf; i++) if (strncmp(f[i], "MD:Z:", 5) == 0) snprintf(r->md, sizeof r->md, "%s", f[i] + 5);
@@ -256,7 +272,7 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
     c->readlength = r->hdr_readlength;
     if (!c->R || !c->frag_counts) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
     if (o->format == 2) {
-        bam = bam_open(path);
+        bam = bam_open(path, r);
         if (!bam) FAIL(EMSAR_HOST_ERR_IO, "can't open BAM file %s", path);
     } else {
         lr = emsar_lr_open(path);
@@ -277,7 +293,7 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
             if (st < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "malformed %s record", bam ? "BAM" : "SAM");
             if (r1.unaligned) continue;                               /* core.tid == -1 (359, 515) */
             if (!o->pe) {
-                int32_t tid = emsar_rsh_tid_of(r, r1.rname);
+                int32_t tid = r1.tid >= 0 ? r1.tid : emsar_rsh_tid_of(r, r1.rname);
                 if (tid < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "unknown transcript %s in the alignment file", r1.rname);
                 char strand = (r1.flag & 0x10) ? '-' : '+';
                 rid = r1.qname;
@@ -289,7 +305,7 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
                 else { char *l2 = emsar_lr_next(lr); st = l2 ? sam_parse(l2, &r2) : 0; }
                 if (st == 0) break;
                 if (st < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "malformed %s record", bam ? "BAM" : "SAM");
-                int32_t tid = emsar_rsh_tid_of(r, r1.rname);
+                int32_t tid = r1.tid >= 0 ? r1.tid : emsar_rsh_tid_of(r, r1.rname);
                 if (tid < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "unknown transcript %s in the alignment file", r1.rname);
                 if (c->readlength == -1) c->readlength = r1.l_seq;
                 if (c->readlength != r1.l_seq || c->readlength != r2.l_seq) FAIL(EMSAR_HOST_ERR_FORMAT, "paired-end data with variable read length is not supported");
