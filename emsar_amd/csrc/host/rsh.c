@@ -21,29 +21,51 @@
 #include <string.h>
 #include <zlib.h>
 
-/* ---------- growing line reader over zlib (reads plain text and .gz alike) ---------- */
-typedef struct { gzFile f; char *buf; size_t cap; } linereader;
+/* ---------- line reader over zlib (reads plain text and .gz alike) ----------
+ * gzread() in 4 MiB pieces and memchr() for the line ends: gzgets() costs more per line than the parsing of a bowtie
+ * record does.  A returned line is NUL-terminated in place and stays valid until the next call. */
+typedef struct { gzFile f; char *buf; size_t cap, pos, len; int eof; } linereader;
 
 static int lr_open(linereader *lr, const char *path) {
     lr->f = (path && strcmp(path, "-") != 0 && path[0]) ? gzopen(path, "rb") : gzdopen(0, "rb");
-    lr->cap = 1 << 16;
-    lr->buf = (char *)malloc(lr->cap);
+    lr->cap = (size_t)4 << 20;
+    lr->buf = (char *)malloc(lr->cap + 1);
+    lr->pos = lr->len = 0; lr->eof = 0;
+    if (lr->f) gzbuffer(lr->f, 1u << 20);
     return (lr->f && lr->buf) ? 0 : -1;
 }
-/* returns NULL at EOF; strips the trailing newline */
+/* returns NULL at EOF (or when out of memory / on a read error); strips the trailing newline and a CR before it */
 static char *lr_next(linereader *lr) {
-    size_t n = 0;
     for (;;) {
-        if (!gzgets(lr->f, lr->buf + n, (int)(lr->cap - n))) { if (n == 0) return NULL; break; }
-        n += strlen(lr->buf + n);
-        if (n && lr->buf[n - 1] == '\n') { lr->buf[--n] = 0; break; }
-        if (n + 1 < lr->cap) break;   /* EOF without newline */
-        char *nb = (char *)realloc(lr->buf, lr->cap * 2);
-        if (!nb) return NULL;
-        lr->buf = nb; lr->cap *= 2;
+        char *start = lr->buf + lr->pos;
+        char *nl = lr->len > lr->pos ? (char *)memchr(start, '\n', lr->len - lr->pos) : NULL;
+        if (nl) {
+            *nl = 0;
+            lr->pos = (size_t)(nl - lr->buf) + 1;
+            if (nl > start && nl[-1] == '\r') nl[-1] = 0;
+            return start;
+        }
+        if (lr->eof) {                                   /* last line without a newline */
+            if (lr->pos >= lr->len) return NULL;
+            lr->buf[lr->len] = 0;
+            lr->pos = lr->len;
+            size_t n = strlen(start);
+            if (n && start[n - 1] == '\r') start[n - 1] = 0;
+            return start;
+        }
+        /* move the unfinished line to the front, grow if it fills the buffer, read on */
+        size_t rest = lr->len - lr->pos;
+        if (lr->pos > 0) { memmove(lr->buf, start, rest); lr->pos = 0; lr->len = rest; }
+        if (lr->len == lr->cap) {
+            char *nb = (char *)realloc(lr->buf, lr->cap * 2 + 1);
+            if (!nb) return NULL;
+            lr->buf = nb; lr->cap *= 2;
+        }
+        int got = gzread(lr->f, lr->buf + lr->len, (unsigned)(lr->cap - lr->len));
+        if (got < 0) return NULL;
+        if (got == 0) lr->eof = 1;
+        lr->len += (size_t)got;
     }
-    if (n && lr->buf[n - 1] == '\r') lr->buf[n - 1] = 0;
-    return lr->buf;
 }
 static void lr_close(linereader *lr) { if (lr->f) gzclose(lr->f); free(lr->buf); }
 

@@ -234,3 +234,38 @@ def test_rsh_binary_cache_refuses_bad_files(tmp_path):
     with pytest.raises(HL.HostError):
         HL.HostRsh(src, cache=cache)
     HL.HostRsh(src, cache=cache, check_source=False)             # explicit opt-out of the staleness check
+
+
+def test_line_reader_edge_cases(tmp_path):
+    """The chunked line reader behind every text input: empty lines, CRLF, a line longer than its 4 MiB buffer, a last
+    line without newline, plain and gzip."""
+    import ctypes as C
+    import gzip
+    lib = HL.lib()
+    lib.emsar_lr_open.restype = C.c_void_p
+    lib.emsar_lr_open.argtypes = [C.c_char_p]
+    lib.emsar_lr_next.restype = C.c_char_p
+    lib.emsar_lr_next.argtypes = [C.c_void_p]
+    lib.emsar_lr_close.argtypes = [C.c_void_p]
+    lines = ["first", "", "crlf\r", "x" * (9 << 20), "tab\tsep", "", "last without newline"]
+    raw = ("\n".join(lines)).encode()
+    want = [ln.rstrip("\r").encode() for ln in lines]
+    for name, opener in (("plain.txt", open), ("packed.gz", gzip.open)):
+        p = str(tmp_path / name)
+        with opener(p, "wb") as f:
+            f.write(raw)
+        h = lib.emsar_lr_open(p.encode())
+        assert h
+        got = []
+        while True:
+            ln = lib.emsar_lr_next(h)
+            if ln is None:
+                break
+            got.append(ln)
+        lib.emsar_lr_close(h)
+        assert got == want
+    p = str(tmp_path / "empty.txt")
+    open(p, "wb").close()
+    h = lib.emsar_lr_open(p.encode())
+    assert lib.emsar_lr_next(h) is None
+    lib.emsar_lr_close(h)
