@@ -17,6 +17,10 @@
  */
 #include "emsar_host.h"
 
+#include <pthread.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -26,6 +30,9 @@
 void *emsar_lr_open(const char *path);
 char *emsar_lr_next(void *h);
 void emsar_lr_close(void *h);
+int64_t emsar_lr_offset(void *h);
+int emsar_lr_is_plain(void *h);
+void *emsar_lr_open_at(const char *path, int64_t offset);
 
 /* One SAM/BAM alignment record reduced to what the reference reads from bam1_t (emsar_functions.c:391-469):
  * qname, flag, reference name, 0-based position, l_qseq and the MD:Z string. */
@@ -253,11 +260,20 @@ static int mate_id_len(const char *a, const char *b) {
 
 #define FAIL(code, ...) do { if (err) snprintf(err, errlen, __VA_ARGS__); rc = (code); goto done; } while (0)
 
-int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln_opts *o, emsar_counts **out,
-                           char *err, size_t errlen) {
+/* One worker of emsar_count_alignments: the read groups of a byte range [begin, end) of a plain text file (end < 0: to
+ * the end of the file; begin = 0 and end < 0: the whole input, any format).  Groups are runs of KEPT records with one
+ * read id (filtered records do not break a run, emsar_functions.c:748,815), so the ranges are stitched on kept
+ * records: a worker with begin > 0 skips the group of its first kept record (the worker on its left finishes that
+ * group, wherever it started), and every worker stops at the first kept record that follows the group of the first
+ * kept record at or after `end`.  *got_group = 0 when the range held no group at all. */
+static int count_range(const emsar_rsh *r, const char *path, const emsar_aln_opts *o, int64_t begin, int64_t end,
+                       emsar_counts **out, int *got_group, char *err, size_t errlen) {
     int rc = EMSAR_HOST_OK;
-    *out = NULL;
+    *out = NULL; *got_group = 0;
     emsar_counts *c = (emsar_counts *)calloc(1, sizeof(*c));
+    int skipping = begin > 0, end_seen = 0, pe_align = begin > 0;
+    char *skip_id = NULL, *end_id = NULL;
+    int64_t rec_off = 0;
     void *lr = NULL;
     bamreader *bam = NULL;
     alist l = {NULL, 0, 0, 10000};
@@ -275,7 +291,7 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
         bam = bam_open(path, r);
         if (!bam) FAIL(EMSAR_HOST_ERR_IO, "can't open BAM file %s", path);
     } else {
-        lr = emsar_lr_open(path);
+        lr = begin > 0 ? emsar_lr_open_at(path, begin) : emsar_lr_open(path);
         if (!lr) FAIL(EMSAR_HOST_ERR_IO, "can't open alignment file %s", path);
     }
 
@@ -288,7 +304,7 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
         if (o->format != 0) {                                        /* ---------- SAM text / BAM ---------- */
             int st;
             if (bam) st = bam_next(bam, &r1);
-            else { line = emsar_lr_next(lr); st = line ? sam_parse(line, &r1) : -2; if (st == 0) continue; if (st == -2) st = 0; }
+            else { line = emsar_lr_next(lr); if (line) rec_off = emsar_lr_offset(lr); st = line ? sam_parse(line, &r1) : -2; if (st == 0) continue; if (st == -2) st = 0; }
             if (st == 0) break;
             if (st < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "malformed %s record", bam ? "BAM" : "SAM");
             if (r1.unaligned) continue;                               /* core.tid == -1 (359, 515) */
@@ -322,6 +338,7 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
         } else if (!(line = emsar_lr_next(lr))) {
             break;
         } else if (!o->pe) {                                          /* ---------- default bowtie, single-end (552-587) ---------- */
+            rec_off = emsar_lr_offset(lr);
             char *f[9];
             int nf = split_tabs(line, f, 9);
             if (nf < 7) FAIL(EMSAR_HOST_ERR_FORMAT, "input alignment file doesn't look like a bowtie output file");
@@ -333,6 +350,12 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
                 x.tid = tid; x.pos = atoi(f[3]); x.fraglen = (int32_t)strlen(f[4]); x.mm = parse_mmstr(nf > 7 ? f[7] : ""); keep = 1;
             }
         } else {                                                      /* ---------- default bowtie, paired-end (612-703) ---------- */
+            if (pe_align) {                                           /* a range may begin on the second mate of a pair: it belongs to the left */
+                pe_align = 0;
+                const char *tab = strchr(line, '\t');
+                if (tab && tab - line >= 2 && tab[-2] == '/' && tab[-1] == '2') continue;
+            }
+            rec_off = emsar_lr_offset(lr);
             size_t n1 = strlen(line) + 1;
             char *keep1 = (char *)realloc(line2, n1);
             if (!keep1) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
@@ -362,6 +385,17 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
             }
         }
         if (!keep) continue;                                          /* prev_read_id is untouched by filtered records (748,815) */
+        if (end >= 0 && !end_seen && rec_off >= end) {                /* the first kept record at or after the end of the range */
+            end_seen = 1;
+            end_id = strdup(rid);
+            if (!end_id) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+        }
+        if (skipping) {                                               /* the group of the first kept record is the left neighbour's */
+            if (!skip_id) { skip_id = strdup(rid); if (!skip_id) FAIL(EMSAR_HOST_ERR_OOM, "out of memory"); continue; }
+            if (strcmp(skip_id, rid) == 0) continue;
+            skipping = 0;
+        }
+        if (end_seen && strcmp(end_id, rid) != 0) break;              /* the next range starts here */
         if (have_prev && strcmp(prev, rid) == 0) {
             if (alist_add(&l, x) < 0) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
         } else {
@@ -374,12 +408,118 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
         memcpy(prev, rid, need);
         have_prev = 1;
     }
-    if (l.n == 0) FAIL(EMSAR_HOST_ERR_FORMAT, "no usable alignment in %s (the reference stops with 'NULL alignment list')", path);
-    if (flush_group(r, o, &l, c, &tmp, &tmpcap) < 0) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+    if (l.n > 0) {
+        *got_group = 1;
+        if (flush_group(r, o, &l, c, &tmp, &tmpcap) < 0) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+    }
 done:
     emsar_lr_close(lr);
     bam_close(bam);
-    free(l.a); free(tmp); free(prev); free(line2);
+    free(l.a); free(tmp); free(prev); free(line2); free(skip_id); free(end_id);
+    if (rc != EMSAR_HOST_OK) { emsar_counts_free(c); return rc; }
+    *out = c;
+    return EMSAR_HOST_OK;
+}
+
+/* ---- the ranges of a plain text file counted side by side ---------------------------------------------------------- */
+typedef struct {
+    const emsar_rsh *r; const char *path; const emsar_aln_opts *o; int64_t begin, end;
+    emsar_counts *c; int got, rc; char err[256];
+} range_job;
+static void *range_main(void *a) {
+    range_job *j = (range_job *)a;
+    j->rc = count_range(j->r, j->path, j->o, j->begin, j->end, &j->c, &j->got, j->err, sizeof j->err);
+    return NULL;
+}
+
+/* how many ranges: plain seekable text only (not BAM, gzip, stdin), single-end, or default-bowtie paired-end whose
+ * mates are named .../1 and .../2 (that is how a range finds the start of a pair); one range per 16 MiB at least */
+static int plan_ranges(const char *path, const emsar_aln_opts *o, int64_t *size_out) {
+    *size_out = 0;
+    if (o->format == 2 || !path || !path[0] || strcmp(path, "-") == 0) return 1;
+    if (o->pe && o->format != 0) return 1;
+    struct stat st;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return 1;
+    void *lr = emsar_lr_open(path);
+    if (!lr) return 1;
+    int ok = emsar_lr_is_plain(lr);
+    if (ok && o->pe) {                                   /* first two records must look like  name/1 \t ...  name/2 \t ... */
+        for (int m = 1; m <= 2 && ok; m++) {
+            char *ln = emsar_lr_next(lr);
+            const char *tab = ln ? strchr(ln, '\t') : NULL;
+            ok = tab && tab - ln >= 2 && tab[-2] == '/' && tab[-1] == (char)('0' + m);
+        }
+    }
+    emsar_lr_close(lr);
+    if (!ok) return 1;
+    long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    int nt = nc > 16 ? 16 : nc < 1 ? 1 : (int)nc;
+    const char *e = getenv("EMSAR_HOST_THREADS");
+    if (e && atoi(e) > 0) nt = atoi(e) > 64 ? 64 : atoi(e);
+    int64_t min_bytes = (int64_t)16 << 20;
+    if ((e = getenv("EMSAR_HOST_RANGE_BYTES")) && atoll(e) > 0) min_bytes = atoll(e);       /* tests use small files */
+    int64_t by_size = (int64_t)st.st_size / min_bytes;
+    if (by_size < nt) nt = by_size < 1 ? 1 : (int)by_size;
+    *size_out = (int64_t)st.st_size;
+    return nt;
+}
+
+int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln_opts *o, emsar_counts **out,
+                           char *err, size_t errlen) {
+    *out = NULL;
+    int64_t size = 0;
+    const int nt = plan_ranges(path, o, &size);
+    int rc = EMSAR_HOST_OK, got = 0;
+    if (getenv("EMSAR_HOST_DEBUG")) fprintf(stderr, "emsar_count_alignments: %d range(s) over %lld bytes\n", nt, (long long)size);
+    if (nt <= 1) {
+        rc = count_range(r, path, o, 0, -1, out, &got, err, errlen);
+        if (rc == EMSAR_HOST_OK && !got) {
+            emsar_counts_free(*out); *out = NULL;
+            if (err) snprintf(err, errlen, "no usable alignment in %s (the reference stops with 'NULL alignment list')", path);
+            return EMSAR_HOST_ERR_FORMAT;
+        }
+        return rc;
+    }
+    range_job *job = (range_job *)calloc((size_t)nt, sizeof(*job));
+    pthread_t *th = (pthread_t *)calloc((size_t)nt, sizeof(*th));
+    if (!job || !th) { free(job); free(th); return EMSAR_HOST_ERR_OOM; }
+    for (int t = 0; t < nt; t++) {
+        job[t].r = r; job[t].path = path; job[t].o = o;
+        job[t].begin = size / nt * t; job[t].end = t + 1 < nt ? size / nt * (t + 1) : -1;
+    }
+    int started = 0;
+    for (int t = 1; t < nt; t++) { if (pthread_create(&th[t], NULL, range_main, &job[t]) != 0) break; started = t; }
+    for (int t = started + 1; t < nt; t++) range_main(&job[t]);      /* could not spawn: run it here */
+    range_main(&job[0]);
+    for (int t = 1; t <= started; t++) pthread_join(th[t], NULL);
+    emsar_counts *c = NULL;
+    for (int t = 0; t < nt; t++) {                                   /* the first failing range (in file order) names the error */
+        if (job[t].rc != EMSAR_HOST_OK && rc == EMSAR_HOST_OK) { rc = job[t].rc; if (err) snprintf(err, errlen, "%s", job[t].err); }
+        got |= job[t].got;
+    }
+    if (rc == EMSAR_HOST_OK && !got) {
+        rc = EMSAR_HOST_ERR_FORMAT;
+        if (err) snprintf(err, errlen, "no usable alignment in %s (the reference stops with 'NULL alignment list')", path);
+    }
+    if (rc == EMSAR_HOST_OK) {
+        c = job[0].c; job[0].c = NULL;
+        for (int t = 1; t < nt && rc == EMSAR_HOST_OK; t++) {
+            const emsar_counts *q = job[t].c;
+            for (int64_t i = 0; i < c->n_rows; i++) c->R[i] += q->R[i];
+            for (int32_t i = 0; i < c->n_frag; i++) c->frag_counts[i] += q->frag_counts[i];
+            c->total_reads += q->total_reads; c->reads_seen += q->reads_seen; c->reads_over_k += q->reads_over_k;
+            c->reads_bad_fraglen += q->reads_bad_fraglen; c->reads_discrepant += q->reads_discrepant; c->reads_no_segment += q->reads_no_segment;
+            if (q->readlength != r->hdr_readlength) {                /* learnt from the data (paired-end, header says -1) */
+                if (c->readlength == r->hdr_readlength) c->readlength = q->readlength;
+                else if (c->readlength != q->readlength) {
+                    rc = EMSAR_HOST_ERR_FORMAT;
+                    if (err) snprintf(err, errlen, "paired-end data with variable read length is not supported");
+                }
+            }
+        }
+    }
+    for (int t = 0; t < nt; t++) emsar_counts_free(job[t].c);
+    free(job); free(th);
     if (rc != EMSAR_HOST_OK) { emsar_counts_free(c); return rc; }
     *out = c;
     return EMSAR_HOST_OK;

@@ -24,13 +24,13 @@
 /* ---------- line reader over zlib (reads plain text and .gz alike) ----------
  * gzread() in 4 MiB pieces and memchr() for the line ends: gzgets() costs more per line than the parsing of a bowtie
  * record does.  A returned line is NUL-terminated in place and stays valid until the next call. */
-typedef struct { gzFile f; char *buf; size_t cap, pos, len; int eof; } linereader;
+typedef struct { gzFile f; char *buf; size_t cap, pos, len; int eof; int64_t base /* file offset of buf[0] */, last /* of the last returned line */; } linereader;
 
 static int lr_open(linereader *lr, const char *path) {
     lr->f = (path && strcmp(path, "-") != 0 && path[0]) ? gzopen(path, "rb") : gzdopen(0, "rb");
     lr->cap = (size_t)4 << 20;
     lr->buf = (char *)malloc(lr->cap + 1);
-    lr->pos = lr->len = 0; lr->eof = 0;
+    lr->pos = lr->len = 0; lr->eof = 0; lr->base = 0; lr->last = 0;
     if (lr->f) gzbuffer(lr->f, 1u << 20);
     return (lr->f && lr->buf) ? 0 : -1;
 }
@@ -41,6 +41,7 @@ static char *lr_next(linereader *lr) {
         char *nl = lr->len > lr->pos ? (char *)memchr(start, '\n', lr->len - lr->pos) : NULL;
         if (nl) {
             *nl = 0;
+            lr->last = lr->base + (int64_t)lr->pos;
             lr->pos = (size_t)(nl - lr->buf) + 1;
             if (nl > start && nl[-1] == '\r') nl[-1] = 0;
             return start;
@@ -48,6 +49,7 @@ static char *lr_next(linereader *lr) {
         if (lr->eof) {                                   /* last line without a newline */
             if (lr->pos >= lr->len) return NULL;
             lr->buf[lr->len] = 0;
+            lr->last = lr->base + (int64_t)lr->pos;
             lr->pos = lr->len;
             size_t n = strlen(start);
             if (n && start[n - 1] == '\r') start[n - 1] = 0;
@@ -55,7 +57,7 @@ static char *lr_next(linereader *lr) {
         }
         /* move the unfinished line to the front, grow if it fills the buffer, read on */
         size_t rest = lr->len - lr->pos;
-        if (lr->pos > 0) { memmove(lr->buf, start, rest); lr->pos = 0; lr->len = rest; }
+        if (lr->pos > 0) { memmove(lr->buf, start, rest); lr->base += (int64_t)lr->pos; lr->pos = 0; lr->len = rest; }
         if (lr->len == lr->cap) {
             char *nb = (char *)realloc(lr->buf, lr->cap * 2 + 1);
             if (!nb) return NULL;
@@ -73,6 +75,18 @@ static void lr_close(linereader *lr) { if (lr->f) gzclose(lr->f); free(lr->buf);
 void *emsar_lr_open(const char *path) { linereader *lr = (linereader *)calloc(1, sizeof(*lr)); if (!lr) return NULL; if (lr_open(lr, path)) { lr_close(lr); free(lr); return NULL; } return lr; }
 char *emsar_lr_next(void *h) { return lr_next((linereader *)h); }
 void emsar_lr_close(void *h) { if (h) { lr_close((linereader *)h); free(h); } }
+/* for the chunked readers of align.c: offset of the line returned last; plain (seekable, uncompressed) file?; open a
+ * plain file so that the first line returned is the first one STARTING at or after `offset` */
+int64_t emsar_lr_offset(void *h) { return ((linereader *)h)->last; }
+int emsar_lr_is_plain(void *h) { return gzdirect(((linereader *)h)->f) ? 1 : 0; }
+void *emsar_lr_open_at(const char *path, int64_t offset) {
+    linereader *lr = (linereader *)emsar_lr_open(path);
+    if (!lr || offset <= 0) return lr;
+    if (gzseek(lr->f, (z_off_t)(offset - 1), SEEK_SET) < 0) { emsar_lr_close(lr); return NULL; }
+    lr->base = offset - 1;
+    if (!lr_next(lr)) { lr->eof = 1; lr->pos = lr->len; }      /* the rest of the line that holds byte offset-1 (just "\n" if a line starts at offset) */
+    return lr;
+}
 
 /* ---------- name -> tid (the reference uses a character trie, stringhash.c) ---------- */
 typedef struct { uint32_t cap; int32_t *slot; char **names; } name_index;
