@@ -22,6 +22,8 @@
 //   * rows longer than kMaxRowLen go to a leftover CSR processed by the generic kernel.
 #pragma once
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
@@ -37,6 +39,7 @@ constexpr int kRowsPerLane = 12;       // twelve 10-bit ids per int4
 constexpr int kTileSliceRows = 64 * kRowsPerLane;   // 768
 constexpr int kTileRows = kTileSlices * kTileSliceRows;
 constexpr int kTileDict = 959;         // theta + acc windows in LDS: 2 x 7.5 KiB; +1 zero slot (5 workgroups per CU)
+constexpr int64_t kFragRows = 1 << 21;   // sorted rows per independently tiled fragment (build_tiled)
 constexpr int kMaxRowLen = 768;        // longer rows -> leftover CSR (a row must fit one dictionary)
 constexpr int kSegRows = 11;           // row ids per backward segment (plus 1 header = 12 x 10 bit = one int4)
 constexpr int kSliceDwords = kTileSliceRows / 3;    // dwords per forward column of a slice (256 = 1 KiB)
@@ -219,164 +222,211 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     std::vector<uint32_t>().swap(pa);
 
     // ---- tiles ----
+    // The sorted rows are cut into fragments of kFragRows rows; every fragment is tiled on its own (into a private
+    // TiledLayout) and the fragments are concatenated.  The cut points depend on the data only, so the layout is the same
+    // whatever the number of host threads that happen to build it.
+    auto form_tiles = [&](int64_t range_begin, int64_t range_end, TiledLayout &out) -> int {
     std::vector<int32_t> stamp((size_t)n_tx, -1), loc((size_t)n_tx, 0);
-    std::vector<int32_t> distinct;
-    std::vector<uint32_t> pairs, sorted;   // (col_local << 16) | row_in_slice
-    std::vector<uint32_t> ccount, fill;
-    std::vector<uint32_t> segs;            // 4 dwords per segment
-    int64_t i0 = 0;
-    int32_t tile_id = 0;
-    while (i0 < n_act) {
-        // 1. how many rows fit: row cap, entry cap, distinct-tid cap
-        distinct.clear();
-        int64_t ents = 0, i1 = i0;
-        while (i1 < n_act && i1 - i0 < tile_rows) {
-            uint32_t r = perm[(size_t)i1];
-            uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-            if (i1 > i0 && ents + (int64_t)(e - b) > kTileEntries) break;
-            size_t before = distinct.size();
-            for (uint64_t k = b; k < e; k++) {
-                int32_t t = col_idx[k];
-                if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
-            }
-            if (i1 > i0 && (int64_t)distinct.size() > kTileDict) {   // undo this row, close the tile
-                for (size_t q = before; q < distinct.size(); q++) stamp[(size_t)distinct[q]] = -1;
-                distinct.resize(before);
-                break;
-            }
-            ents += (int64_t)(e - b);
-            i1++;
-        }
-        if ((int64_t)distinct.size() > kTileDict) return -3;       // a single row with too many tids: excluded by kMaxRowLen
-        // a tile closed by the dictionary or entry cap in the middle of a slice would pad that slice with empty rows
-        // (forward bytes and gathers for nothing): give the rows of the started slice to the next tile instead
-        if (cut_at_slices && i1 < n_act && i1 - i0 > kTileSliceRows && (i1 - i0) % kTileSliceRows != 0) {
-            const int64_t keep = (i1 - i0) / kTileSliceRows * kTileSliceRows;
-            for (int32_t t : distinct) stamp[(size_t)t] = -1;
+        std::vector<int32_t> distinct;
+        std::vector<uint32_t> pairs, sorted;   // (col_local << 16) | row_in_slice
+        std::vector<uint32_t> ccount, fill;
+        std::vector<uint32_t> segs;            // 4 dwords per segment
+        int64_t i0 = range_begin;
+        int32_t tile_id = 0;
+        const int64_t n_act = range_end;      // rows beyond the range belong to another fragment
+        while (i0 < n_act) {
+            // 1. how many rows fit: row cap, entry cap, distinct-tid cap
             distinct.clear();
-            i1 = i0 + keep;
-            for (int64_t i = i0; i < i1; i++) {
-                uint32_t r = perm[(size_t)i];
-                for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+            int64_t ents = 0, i1 = i0;
+            while (i1 < n_act && i1 - i0 < tile_rows) {
+                uint32_t r = perm[(size_t)i1];
+                uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+                if (i1 > i0 && ents + (int64_t)(e - b) > kTileEntries) break;
+                size_t before = distinct.size();
+                for (uint64_t k = b; k < e; k++) {
                     int32_t t = col_idx[k];
                     if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
                 }
-            }
-        }
-        // 2. dictionary: the contiguous tid range [distinct[a], distinct[c]] that covers the MOST of the tile's
-        //    tids while (range length + tids outside it) still fits; the tids outside (cross-family hits on
-        //    either side) go to the explicit far list.  slots(a,c) = n + (tids missing inside the range).
-        std::sort(distinct.begin(), distinct.end());
-        const size_t n = distinct.size();
-        size_t best_a = 0, best_c = 0, a = 0;
-        for (size_t c = 0; c < n; c++) {
-            while ((int64_t)n + ((int64_t)distinct[c] - distinct[a]) - (int64_t)(c - a) > kTileDict) a++;
-            if (c == 0 || c - a > best_c - best_a) { best_a = a; best_c = c; }
-        }
-        const int32_t lo = distinct[best_a];
-        const int32_t near_n = distinct[best_c] - lo + 1;
-        const int32_t far_n = (int32_t)(n - (best_c - best_a + 1));
-        Tile T;
-        std::memset(&T, 0, sizeof T);
-        T.lo = lo; T.near_n = (uint16_t)near_n; T.far_n = (uint16_t)far_n;
-        T.far_off = (uint32_t)out.far_tid.size();
-        for (size_t q = 0; q < distinct.size(); q++) {
-            int32_t t = distinct[q];
-            if (t >= lo && t - lo < near_n) loc[(size_t)t] = t - lo;
-            else { loc[(size_t)t] = near_n + (int32_t)(out.far_tid.size() - T.far_off); out.far_tid.push_back(t); }
-        }
-        const int nd = near_n + far_n;
-        const uint32_t zero_id = (uint32_t)nd;                         // th_w[nd] = 0
-        const uint32_t pad_row = (uint32_t)kTileSliceRows;             // w_r[768] of every slice = 0
-        const int64_t nrow = i1 - i0;
-        T.n_slices = (uint16_t)((nrow + kTileSliceRows - 1) / kTileSliceRows);
-        T.row_base = (uint32_t)out.slot_row.size();
-        out.slot_row.resize(out.slot_row.size() + (size_t)T.n_slices * kTileSliceRows, -1);
-        T.fwd_off = (uint64_t)out.fwd.size() * 4;
-        T.bwd_off = (uint64_t)out.bwd.size() * 4;
-        T.coo_off = (uint32_t)out.coo.size();
-        out.n_fslices += T.n_slices;
-        // 3. forward slices (all of them first: the tile's forward block is contiguous).  Column j of a slice is 256
-        //    dwords; row p of the slice (p = position in sorted order) is field p/64 of the int4 of lane p%64: the 64
-        //    lanes of one E-step gather read 64 CONSECUTIVE sorted rows, i.e. mostly one family -- the same few
-        //    dictionary slots (LDS broadcast) or neighbouring ones (distinct banks) instead of a random spread
-        uint32_t zero_dword = zero_id | (zero_id << 10) | (zero_id << 20);
-        for (int s = 0; s < T.n_slices; s++) {
-            int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
-            int64_t k = 0;
-            for (int64_t i = a0; i < bnd; i++) { uint32_t r = perm[(size_t)i]; k = std::max<int64_t>(k, (int64_t)(row_ptr[r + 1] - row_ptr[r])); }
-            T.k[s] = (uint16_t)k;
-            size_t base = out.fwd.size();
-            out.fwd.resize(base + (size_t)k * kSliceDwords, zero_dword);
-            out.padded_slots += k * kTileSliceRows;
-            for (int64_t i = a0; i < bnd; i++) {
-                uint32_t r = perm[(size_t)i];
-                uint32_t in_slice = (uint32_t)(i - a0);
-                out.slot_row[(size_t)T.row_base + (size_t)s * kTileSliceRows + in_slice] = (int64_t)r;
-                uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-                for (uint64_t q = b; q < e; q++) {
-                    int32_t d = loc[(size_t)col_idx[q]];
-                    const uint32_t fl = in_slice & 63u, fi = in_slice >> 6;      // lane, field: see slot numbering above
-                    uint32_t *dw = &out.fwd[base + (size_t)(q - b) * kSliceDwords + fl * 4 + fi / 3];
-                    const int sh = 10 * (int)(fi % 3);
-                    *dw = (*dw & ~(0x3FFu << sh)) | ((uint32_t)d << sh);
-                    if (d >= near_n) out.far_entries++;
+                if (i1 > i0 && (int64_t)distinct.size() > kTileDict) {   // undo this row, close the tile
+                    for (size_t q = before; q < distinct.size(); q++) stamp[(size_t)distinct[q]] = -1;
+                    distinct.resize(before);
+                    break;
                 }
-                out.tiled_entries += (int64_t)(e - b);
+                ents += (int64_t)(e - b);
+                i1++;
             }
-        }
-        // 4. backward index of each slice: its (column, row) pairs sorted by column
-        for (int s = 0; s < T.n_slices; s++) {
-            int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
-            pairs.clear();
-            for (int64_t i = a0; i < bnd; i++) {
-                uint32_t r = perm[(size_t)i];
-                uint32_t in_slice = (uint32_t)(i - a0);
-                for (uint64_t q = row_ptr[r]; q < row_ptr[r + 1]; q++) pairs.push_back(((uint32_t)loc[(size_t)col_idx[q]] << 16) | in_slice);
-            }
-            ccount.assign((size_t)nd + 1, 0);
-            for (uint32_t p : pairs) ccount[(p >> 16) + 1]++;
-            for (int d = 0; d < nd; d++) ccount[(size_t)d + 1] += ccount[(size_t)d];
-            sorted.resize(pairs.size());
-            fill.assign(ccount.begin(), ccount.end() - 1);
-            for (uint32_t p : pairs) sorted[fill[p >> 16]++] = p;
-            segs.clear();
-            size_t coo_before = out.coo.size();
-            for (int d = 0; d < nd; d++) {
-                uint32_t b = ccount[(size_t)d], e = ccount[(size_t)d + 1];
-                if (e - b < (uint32_t)kDenseMin) {
-                    for (uint32_t q = b; q < e; q++) out.coo.push_back(((uint32_t)d << 16) | (sorted[q] & 0xFFFF));
-                    continue;
-                }
-                for (uint32_t q = b; q < e; q += kSegRows) {
-                    uint32_t seg[4] = {0, 0, 0, 0};
-                    pack10(seg, 0, (uint32_t)d);
-                    for (uint32_t j = 0; j < (uint32_t)kSegRows; j++) pack10(seg, 1 + (int)j, q + j < e ? (sorted[q + j] & 0xFFFF) : pad_row);
-                    segs.insert(segs.end(), seg, seg + 4);
+            if ((int64_t)distinct.size() > kTileDict) return -3;       // a single row with too many tids: excluded by kMaxRowLen
+            // a tile closed by the dictionary or entry cap in the middle of a slice would pad that slice with empty rows
+            // (forward bytes and gathers for nothing): give the rows of the started slice to the next tile instead
+            if (cut_at_slices && i1 < n_act && i1 - i0 > kTileSliceRows && (i1 - i0) % kTileSliceRows != 0) {
+                const int64_t keep = (i1 - i0) / kTileSliceRows * kTileSliceRows;
+                for (int32_t t : distinct) stamp[(size_t)t] = -1;
+                distinct.clear();
+                i1 = i0 + keep;
+                for (int64_t i = i0; i < i1; i++) {
+                    uint32_t r = perm[(size_t)i];
+                    for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+                        int32_t t = col_idx[k];
+                        if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
+                    }
                 }
             }
-            T.coo_n[s] = (uint16_t)(out.coo.size() - coo_before);
-            out.coo_entries += T.coo_n[s];
-            const int64_t nseg = (int64_t)segs.size() / 4;
-            const int m = (int)((nseg + 63) / 64);
-            T.m[s] = (uint16_t)m;
-            size_t base = out.bwd.size();
-            uint32_t empty[4] = {0, 0, 0, 0};                          // unused segment: zero column, padding rows
-            pack10(empty, 0, zero_id);
-            for (int j = 1; j < 12; j++) pack10(empty, j, pad_row);
-            out.bwd.resize(base + (size_t)m * 64 * 4);
-            for (int64_t g = 0; g < (int64_t)m * 64; g++) {
-                // logical segment g -> lane g / m, unit g % m ; physical int4 index (unit*64 + lane)
-                int64_t lane = g / m, unit = g % m;
-                size_t u0 = base + (size_t)((unit * 64 + lane) * 4);
-                const uint32_t *src = g < nseg ? &segs[(size_t)g * 4] : empty;
-                for (int w = 0; w < 4; w++) out.bwd[u0 + (size_t)w] = src[w];
+            // 2. dictionary: the contiguous tid range [distinct[a], distinct[c]] that covers the MOST of the tile's
+            //    tids while (range length + tids outside it) still fits; the tids outside (cross-family hits on
+            //    either side) go to the explicit far list.  slots(a,c) = n + (tids missing inside the range).
+            std::sort(distinct.begin(), distinct.end());
+            const size_t n = distinct.size();
+            size_t best_a = 0, best_c = 0, a = 0;
+            for (size_t c = 0; c < n; c++) {
+                while ((int64_t)n + ((int64_t)distinct[c] - distinct[a]) - (int64_t)(c - a) > kTileDict) a++;
+                if (c == 0 || c - a > best_c - best_a) { best_a = a; best_c = c; }
             }
+            const int32_t lo = distinct[best_a];
+            const int32_t near_n = distinct[best_c] - lo + 1;
+            const int32_t far_n = (int32_t)(n - (best_c - best_a + 1));
+            Tile T;
+            std::memset(&T, 0, sizeof T);
+            T.lo = lo; T.near_n = (uint16_t)near_n; T.far_n = (uint16_t)far_n;
+            T.far_off = (uint32_t)out.far_tid.size();
+            for (size_t q = 0; q < distinct.size(); q++) {
+                int32_t t = distinct[q];
+                if (t >= lo && t - lo < near_n) loc[(size_t)t] = t - lo;
+                else { loc[(size_t)t] = near_n + (int32_t)(out.far_tid.size() - T.far_off); out.far_tid.push_back(t); }
+            }
+            const int nd = near_n + far_n;
+            const uint32_t zero_id = (uint32_t)nd;                         // th_w[nd] = 0
+            const uint32_t pad_row = (uint32_t)kTileSliceRows;             // w_r[768] of every slice = 0
+            const int64_t nrow = i1 - i0;
+            T.n_slices = (uint16_t)((nrow + kTileSliceRows - 1) / kTileSliceRows);
+            T.row_base = (uint32_t)out.slot_row.size();
+            out.slot_row.resize(out.slot_row.size() + (size_t)T.n_slices * kTileSliceRows, -1);
+            T.fwd_off = (uint64_t)out.fwd.size() * 4;
+            T.bwd_off = (uint64_t)out.bwd.size() * 4;
+            T.coo_off = (uint32_t)out.coo.size();
+            out.n_fslices += T.n_slices;
+            // 3. forward slices (all of them first: the tile's forward block is contiguous).  Column j of a slice is 256
+            //    dwords; row p of the slice (p = position in sorted order) is field p/64 of the int4 of lane p%64: the 64
+            //    lanes of one E-step gather read 64 CONSECUTIVE sorted rows, i.e. mostly one family -- the same few
+            //    dictionary slots (LDS broadcast) or neighbouring ones (distinct banks) instead of a random spread
+            uint32_t zero_dword = zero_id | (zero_id << 10) | (zero_id << 20);
+            for (int s = 0; s < T.n_slices; s++) {
+                int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
+                int64_t k = 0;
+                for (int64_t i = a0; i < bnd; i++) { uint32_t r = perm[(size_t)i]; k = std::max<int64_t>(k, (int64_t)(row_ptr[r + 1] - row_ptr[r])); }
+                T.k[s] = (uint16_t)k;
+                size_t base = out.fwd.size();
+                out.fwd.resize(base + (size_t)k * kSliceDwords, zero_dword);
+                out.padded_slots += k * kTileSliceRows;
+                for (int64_t i = a0; i < bnd; i++) {
+                    uint32_t r = perm[(size_t)i];
+                    uint32_t in_slice = (uint32_t)(i - a0);
+                    out.slot_row[(size_t)T.row_base + (size_t)s * kTileSliceRows + in_slice] = (int64_t)r;
+                    uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+                    for (uint64_t q = b; q < e; q++) {
+                        int32_t d = loc[(size_t)col_idx[q]];
+                        const uint32_t fl = in_slice & 63u, fi = in_slice >> 6;      // lane, field: see slot numbering above
+                        uint32_t *dw = &out.fwd[base + (size_t)(q - b) * kSliceDwords + fl * 4 + fi / 3];
+                        const int sh = 10 * (int)(fi % 3);
+                        *dw = (*dw & ~(0x3FFu << sh)) | ((uint32_t)d << sh);
+                        if (d >= near_n) out.far_entries++;
+                    }
+                    out.tiled_entries += (int64_t)(e - b);
+                }
+            }
+            // 4. backward index of each slice: its (column, row) pairs sorted by column
+            for (int s = 0; s < T.n_slices; s++) {
+                int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
+                pairs.clear();
+                for (int64_t i = a0; i < bnd; i++) {
+                    uint32_t r = perm[(size_t)i];
+                    uint32_t in_slice = (uint32_t)(i - a0);
+                    for (uint64_t q = row_ptr[r]; q < row_ptr[r + 1]; q++) pairs.push_back(((uint32_t)loc[(size_t)col_idx[q]] << 16) | in_slice);
+                }
+                ccount.assign((size_t)nd + 1, 0);
+                for (uint32_t p : pairs) ccount[(p >> 16) + 1]++;
+                for (int d = 0; d < nd; d++) ccount[(size_t)d + 1] += ccount[(size_t)d];
+                sorted.resize(pairs.size());
+                fill.assign(ccount.begin(), ccount.end() - 1);
+                for (uint32_t p : pairs) sorted[fill[p >> 16]++] = p;
+                segs.clear();
+                size_t coo_before = out.coo.size();
+                for (int d = 0; d < nd; d++) {
+                    uint32_t b = ccount[(size_t)d], e = ccount[(size_t)d + 1];
+                    if (e - b < (uint32_t)kDenseMin) {
+                        for (uint32_t q = b; q < e; q++) out.coo.push_back(((uint32_t)d << 16) | (sorted[q] & 0xFFFF));
+                        continue;
+                    }
+                    for (uint32_t q = b; q < e; q += kSegRows) {
+                        uint32_t seg[4] = {0, 0, 0, 0};
+                        pack10(seg, 0, (uint32_t)d);
+                        for (uint32_t j = 0; j < (uint32_t)kSegRows; j++) pack10(seg, 1 + (int)j, q + j < e ? (sorted[q + j] & 0xFFFF) : pad_row);
+                        segs.insert(segs.end(), seg, seg + 4);
+                    }
+                }
+                T.coo_n[s] = (uint16_t)(out.coo.size() - coo_before);
+                out.coo_entries += T.coo_n[s];
+                const int64_t nseg = (int64_t)segs.size() / 4;
+                const int m = (int)((nseg + 63) / 64);
+                T.m[s] = (uint16_t)m;
+                size_t base = out.bwd.size();
+                uint32_t empty[4] = {0, 0, 0, 0};                          // unused segment: zero column, padding rows
+                pack10(empty, 0, zero_id);
+                for (int j = 1; j < 12; j++) pack10(empty, j, pad_row);
+                out.bwd.resize(base + (size_t)m * 64 * 4);
+                for (int64_t g = 0; g < (int64_t)m * 64; g++) {
+                    // logical segment g -> lane g / m, unit g % m ; physical int4 index (unit*64 + lane)
+                    int64_t lane = g / m, unit = g % m;
+                    size_t u0 = base + (size_t)((unit * 64 + lane) * 4);
+                    const uint32_t *src = g < nseg ? &segs[(size_t)g * 4] : empty;
+                    for (int w = 0; w < 4; w++) out.bwd[u0 + (size_t)w] = src[w];
+                }
+            }
+            out.tiles.push_back(T);
+            for (int32_t t : distinct) stamp[(size_t)t] = -1;
+            tile_id++;
+            i0 = i1;
         }
-        out.tiles.push_back(T);
-        for (int32_t t : distinct) stamp[(size_t)t] = -1;
-        tile_id++;
-        i0 = i1;
+        return 0;
+    };
+    {
+        int64_t frag_rows = kFragRows;
+        if (const char *e = getenv("EMSAR_HIP_FRAG_ROWS")) { long long v = atoll(e); if (v >= kTileRows) frag_rows = v; }   // tests: many fragments on small inputs
+        const int64_t n_frag = std::max<int64_t>(1, (n_act + frag_rows - 1) / frag_rows);
+        std::vector<TiledLayout> frag((size_t)n_frag);
+        std::vector<int> frc((size_t)n_frag, 0);
+        unsigned hw = std::thread::hardware_concurrency();
+        int nthr = (int)std::min<int64_t>(n_frag, hw ? std::min(hw, 16u) : 1u);
+        if (const char *e = getenv("EMSAR_HOST_THREADS")) { int v = atoi(e); if (v >= 1) nthr = (int)std::min<int64_t>(n_frag, v); }
+        std::atomic<int64_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                const int64_t g = next.fetch_add(1);
+                if (g >= n_frag) break;
+                frc[(size_t)g] = form_tiles(g * frag_rows, std::min(n_act, (g + 1) * frag_rows), frag[(size_t)g]);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthr; t++) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+        for (int64_t g = 0; g < n_frag; g++) if (frc[(size_t)g] != 0) return frc[(size_t)g];
+        for (int64_t g = 0; g < n_frag; g++) {
+            TiledLayout &F = frag[(size_t)g];
+            const uint64_t fwd_b = (uint64_t)out.fwd.size() * 4, bwd_b = (uint64_t)out.bwd.size() * 4;
+            const uint32_t slot_b = (uint32_t)out.slot_row.size(), far_b = (uint32_t)out.far_tid.size(), coo_b = (uint32_t)out.coo.size();
+            for (Tile t : F.tiles) {
+                t.fwd_off += fwd_b; t.bwd_off += bwd_b; t.row_base += slot_b; t.far_off += far_b; t.coo_off += coo_b;
+                out.tiles.push_back(t);
+            }
+            out.slot_row.insert(out.slot_row.end(), F.slot_row.begin(), F.slot_row.end());
+            out.fwd.insert(out.fwd.end(), F.fwd.begin(), F.fwd.end());
+            out.bwd.insert(out.bwd.end(), F.bwd.begin(), F.bwd.end());
+            out.coo.insert(out.coo.end(), F.coo.begin(), F.coo.end());
+            out.far_tid.insert(out.far_tid.end(), F.far_tid.begin(), F.far_tid.end());
+            out.tiled_entries += F.tiled_entries; out.far_entries += F.far_entries; out.coo_entries += F.coo_entries;
+            out.n_fslices += F.n_fslices; out.padded_slots += F.padded_slots;
+            F = TiledLayout();
+        }
     }
     // Largest tiles first: they start while the grid is full, the small ones fill the tail.
     auto work = [](const Tile &t) {

@@ -3,6 +3,7 @@
 #include "../emsar_amd/csrc/layout_tiled.hpp"
 #include "../emsar_amd/csrc/sets.hpp"
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 int main() {
     std::mt19937 rng(1);
@@ -18,6 +19,9 @@ int main() {
             for (int j = 0; j < k; j++) ci.push_back(rng() % 10 == 0 ? (int)(rng() % n_tx) : std::min(n_tx - 1, t0 + j % 64));
             rp.push_back(ci.size());
         }
+        if (trial % 4 == 1) setenv("EMSAR_HIP_FRAG_ROWS", "3072", 1);          // many independently tiled fragments, several threads
+        else if (trial % 4 == 2) setenv("EMSAR_HIP_FRAG_ROWS", "7000", 1);
+        else unsetenv("EMSAR_HIP_FRAG_ROWS");
         for (int merge = 0; merge < 2; merge++) {
             emsar::TiledLayout L;
             int rc = emsar::build_tiled(n_rows, n_tx, rp.data(), ci.data(), L, merge);
