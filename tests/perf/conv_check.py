@@ -1,6 +1,6 @@
 """Diagnostic: convergence of the device solver vs the CPU oracle on a scaled BASELINE config."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from emsar_amd import EmsarHip, synth
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
