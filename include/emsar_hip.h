@@ -70,6 +70,11 @@ typedef struct {
     double  count_floor;  /* optional second floor, in READS: the floor of transcript t becomes max(abs_floor, count_floor/den_t).
                              Transcripts whose optimum is the boundary theta = 0 with zero gradient decay like 1/k; a floor of
                              e.g. 1e-3 inferred reads stops the solve once only such components still move.  0 = off. */
+    double  zero_cut;     /* > 0: a component that is below this value AND still decreasing no longer holds the solve up.  The
+                             reference prints FPKM with "%lf" (emsar_functions.c:3207): anything below 5e-7 is written as
+                             0.000000, so with zero_cut = 2.5e-7 the .fpkm file is the same while the 1/k decay of boundary
+                             components (optimum theta = 0 with zero gradient) stops costing tens of thousands of passes.
+                             <= 0 = off (every component must meet tol). */
 } emsar_em_params;
 
 typedef struct {

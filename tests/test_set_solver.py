@@ -104,3 +104,19 @@ def test_max_iter_is_reported(dev, golden):
     th, st = dev.solve(max_iter=4, accel=1, tol=1e-14, set_mode=0)
     if st.sets_resident:
         assert st.set_passes_max <= 6 and (st.converged == 0) == (st.sets_unconverged > 0)
+
+
+@pytest.mark.parametrize("set_mode", [0, 1])
+def test_zero_cut_stops_earlier_and_prints_the_same(dev, golden, set_mode):
+    """emsar_em_params.zero_cut: components below a quarter of the .fpkm print quantum that are still falling no longer
+    hold the solve up.  Fewer passes, the reference parity criterion still met, nothing moves by more than the quantum."""
+    m = golden.model
+    dev.upload_structure(m.n_tx, m.row_ptr, m.col_idx, LAYOUT_TILED)
+    dev.upload_sample(m.R, m.E, None)
+    strict, st_s = dev.solve(max_iter=600000, tol=1e-10, set_mode=set_mode)
+    quick, st_q = dev.solve(max_iter=600000, tol=1e-10, set_mode=set_mode, zero_cut=2.5e-7)
+    assert st_q.converged == 1
+    if set_mode == 0:                     # resident sets follow the same trajectory up to the stop (no atomics); the streaming
+        assert st_q.iters <= st_s.iters   # solve's pass counts vary from run to run
+    golden.check_fpkm_parity(quick, "zero_cut set_mode=%d" % set_mode)
+    assert np.all(np.abs(quick - strict) <= 1e-6 * np.abs(strict) + 5e-7)
