@@ -202,9 +202,9 @@ def time_to_mle(device):
     th, st = dev.solve(max_iter=200000, tol=1e-10)
     gpu_s = time.perf_counter() - t0
     # the same solve with the stopping rule emsar-hip uses by default: components below a quarter of the .fpkm print
-    # quantum that are still falling do not hold the solve up
+    # quantum that are still falling, or that move by less than 1e-13 FPKM per pass, do not hold the solve up
     t0 = time.perf_counter()
-    th_q, st_q = dev.solve(max_iter=200000, tol=1e-10, zero_cut=2.5e-7)
+    th_q, st_q = dev.solve(max_iter=200000, tol=1e-10, zero_cut=2.5e-7, abs_step=1e-13)
     gpu_q_s = time.perf_counter() - t0
     dev.close()
     F_ref, F = m.loglik(th_ref), m.loglik(th)
@@ -214,7 +214,7 @@ def time_to_mle(device):
             "gpu_sets_streamed": st.sets_streamed, "gpu_converged": bool(st.converged), "set_packing_host_ms": st.sets_build_ms,
             "cpu_reference_algorithm_s": cpu_s, "cpu_cores": cores, "cpu_kind": "port", "cpu_sweeps": int(sweeps),
             "speedup": cpu_s / gpu_s, "loglik_gpu_minus_cpu": F - F_ref, "loglik": F,
-            "print_quantum_stop": {"zero_cut": 2.5e-7, "gpu_s": gpu_q_s, "gpu_em_passes_slowest_set": st_q.set_passes_max,
+            "print_quantum_stop": {"zero_cut": 2.5e-7, "abs_step": 1e-13, "gpu_s": gpu_q_s, "gpu_em_passes_slowest_set": st_q.set_passes_max,
                                    "max_abs_dtheta_vs_strict": float(np.abs(th_q - th).max()),
                                    "printed_differently": int((np.round(th_q, 6) != np.round(th, 6)).sum()), "speedup": cpu_s / gpu_q_s}}
 

@@ -785,7 +785,7 @@ __global__ void k_fill_start(int n, const double *__restrict__ den, double *__re
 // grid-stride, one atomicMax per workgroup (hundreds of same-address atomics cost ~12 ns each)
 __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
                                                 const double *__restrict__ den, const double *__restrict__ u /* folded single-tid rows, may be null */,
-                                                double *__restrict__ th_out, double abs_floor, double count_floor, double zero_cut, Scal *scal,
+                                                double *__restrict__ th_out, double abs_floor, double count_floor, double zero_cut, double abs_step, Scal *scal,
                                                 const uint8_t *__restrict__ kind /* non-null: only KIND_STREAMED transcripts enter the stopping rule */,
                                                 int to_delta1 /* the first (plain) step of a SQUAREM cycle: the cycle's stopping rule */) {
     __shared__ double red[4];
@@ -801,6 +801,7 @@ __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict_
         double dd = fabs(y - x) / (fabs(y) + fl);
         if (!(dd == dd)) dd = __builtin_huge_val();  // NaN -> +inf so that the host sees it
         if (y < zero_cut && y <= x) dd = 0.0;        // below the print quantum and still falling: prints as 0.000000 either way
+        if (fabs(y - x) < abs_step) dd = 0.0;         // moves by less than abs_step per pass (emsar_em_params.abs_step)
         if (kind && kind[t] != emsar::KIND_STREAMED) dd = 0.0;
         d = fmax(d, dd);
     }
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(256) void k_update_p3(int n, const double *__restri
 // step as the streaming solve below, so both reach the same fixed point.
 // ------------------------------------------------------------------------------------------------
 struct SetStat { int32_t passes, converged; double delta; };
-struct SetSolveParams { double tol, abs_floor, count_floor, zero_cut; int32_t max_iter, accel; };
+struct SetSolveParams { double tol, abs_floor, count_floor, zero_cut, abs_step; int32_t max_iter, accel; };
 
 template <int THREADS, int N>
 __device__ __forceinline__ void set_reduce_sum(double (&v)[N], double *red) {
@@ -1035,6 +1036,7 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
             double dd = fabs(y - x) / (fabs(y) + fl);
             if (!(dd == dd)) dd = __builtin_huge_val();
             if (y < P.zero_cut && y <= x) dd = 0.0;
+            if (fabs(y - x) < P.abs_step) dd = 0.0;
             dloc = fmax(dloc, dd);
         }
         delta = set_reduce_max<THREADS>(dloc, L.red);
@@ -1145,11 +1147,14 @@ __global__ void k_closed_form(int n, const uint8_t *__restrict__ kind, const dou
     if (t < n && kind[t] == emsar::KIND_CLOSED) theta[t] = den[t] > 0.0 ? usum[t] / den[t] : 0.0;
 }
 
-__global__ __launch_bounds__(256) void k_sum(int n, const double *__restrict__ x, double *out) {
-    __shared__ double red[4];
-    int t = blockIdx.x * 256 + threadIdx.x;
-    double s = block_sum<256>(t < n ? x[t] : 0.0, red);
-    if (threadIdx.x == 0) atomic_add_f64(out, s);
+// sum of the mean FPKM (the TPM denominator, emsar_functions.c:3176-3181): ONE workgroup, fixed order -- the printed TPM
+// column must not depend on the arrival order of atomics (the per-set solver is bit-reproducible, its output should be too)
+__global__ __launch_bounds__(1024) void k_sum(int n, const double *__restrict__ x, double *out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int t = threadIdx.x; t < n; t += 1024) s += x[t];
+    double tot = block_sum<1024>(s, red);
+    if (threadIdx.x == 0) *out = *out + tot;
 }
 __global__ __launch_bounds__(256) void k_dot(int n, const double *__restrict__ x, const double *__restrict__ y, double *out) {
     __shared__ double red[4];
@@ -1219,7 +1224,7 @@ struct emsar_hip_ctx {
     int64_t bytes_formula = 0, bytes_stored = 0;
     int64_t tl_fwd_slots = 0, tl_n_fslices = 0;
     double count_floor = 0.0;    // stopping-rule floor in reads for the current solve (emsar_em_params.count_floor)
-    double zero_cut = 0.0;       // emsar_em_params.zero_cut of the current solve
+    double zero_cut = 0.0, abs_step = 0.0;   // emsar_em_params.zero_cut / abs_step of the current solve
     int update_grid = 256;       // workgroups of k_update (EMSAR_HIP_UPDATE_GRID)
     int tiled_multi = 2;         // 2: two tiles per workgroup, software-pipelined (k_pass_tiled_multi); 0: one (k_pass_tiled)
     const uint8_t *delta_mask = nullptr;   // d_kind while the streaming solve runs next to resident sets
@@ -1366,7 +1371,7 @@ int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_l
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot]);
     if (rc) return rc;
     hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), ctx->update_grid)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
-                       ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->zero_cut, ctx->d_scal,
+                       ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->zero_cut, ctx->abs_step, ctx->d_scal,
                        ctx->delta_mask, to_delta1);
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
@@ -1796,7 +1801,7 @@ int emsar_hip_run_passes(emsar_hip_ctx *ctx, int32_t n_passes, float *elapsed_ms
 int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_out, emsar_em_stats *stats) {
     if (!ctx || !fpkm_out) return EMSAR_HIP_ERR_ARG;
     if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
-    emsar_em_params p = pp ? *pp : emsar_em_params{0, 1, 0, 0, 0, 0, 0, 0};
+    emsar_em_params p = pp ? *pp : emsar_em_params{0, 1, 0, 0, 0, 0, 0, 0, 0};
     if (p.max_iter <= 0) p.max_iter = 100000;
     if (p.tol <= 0) p.tol = 1e-10;
     if (p.abs_floor <= 0) p.abs_floor = 1e-6;
@@ -1805,6 +1810,7 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     if (p.set_mode != 0 && p.set_mode != 1) return EMSAR_HIP_ERR_ARG;
     ctx->count_floor = p.count_floor;
     ctx->zero_cut = p.zero_cut > 0.0 ? p.zero_cut : 0.0;
+    ctx->abs_step = p.abs_step > 0.0 ? p.abs_step : 0.0;
     ctx->delta_mask = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
     int rc;
@@ -1854,7 +1860,7 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     ctx->delta_mask = nullptr;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (use_sets) {
-        SetSolveParams P{p.tol, p.abs_floor, p.count_floor, p.zero_cut > 0.0 ? p.zero_cut : 0.0, p.max_iter, p.accel};
+        SetSolveParams P{p.tol, p.abs_floor, p.count_floor, p.zero_cut > 0.0 ? p.zero_cut : 0.0, p.abs_step > 0.0 ? p.abs_step : 0.0, p.max_iter, p.accel};
         if ((rc = solve_resident_sets(ctx, P, th[0]))) return rc;
         if (ctx->n_sstat > 0)
             HIPCHK(hipMemcpyAsync(ctx->h_sstat, ctx->d_sstat, (size_t)ctx->n_sstat * sizeof(SetStat), hipMemcpyDeviceToHost, ctx->stream));
@@ -1868,7 +1874,7 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(fpkm_out, th[0], (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->count_floor = 0.0; ctx->zero_cut = 0.0;
+    ctx->count_floor = 0.0; ctx->zero_cut = 0.0; ctx->abs_step = 0.0;
     for (int32_t t = 0; t < n; t++)
         if (!std::isfinite(fpkm_out[t])) { ctx->err = "non-finite theta"; return EMSAR_HIP_ERR_NUMERIC; }
     int32_t set_max = 0, set_unconv = 0;
@@ -1928,7 +1934,7 @@ int emsar_hip_normalise(emsar_hip_ctx *ctx, const double *mean_fpkm, const doubl
     HIPCHK(hipMemcpyAsync(ctx->d_tmp[0], mean_fpkm, B, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_tmp[1], ieuma, B, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(&ctx->d_scal->sum_b, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_sum, dim3(g), dim3(256), 0, ctx->stream, n, ctx->d_tmp[0], &ctx->d_scal->sum_b);
+    hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, ctx->stream, n, ctx->d_tmp[0], &ctx->d_scal->sum_b);
     // tmp[2] <- tpm, acc <- iReadcount (acc is zero between passes and is cleared again below)
     hipLaunchKernelGGL(k_normalise, dim3(g), dim3(256), 0, ctx->stream, n, ctx->d_tmp[0], ctx->d_tmp[1],
                        (double)total_read_count / 1E6, &ctx->d_scal->sum_b, ctx->d_tmp[2], ctx->d_acc, ctx->d_itmp);

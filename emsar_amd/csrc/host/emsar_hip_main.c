@@ -37,7 +37,7 @@ typedef struct {
     char **aln; int n_aln;
     emsar_aln_opts ao;
     int n_round, delta, print_segments, verbose, accel, set_mode;
-    double tol, count_floor, zero_cut; int max_iter;
+    double tol, count_floor, zero_cut, abs_step; int max_iter;
     const char *stats_json;
     const char *rsh_cache;      /* NULL = off, "" = <rsh>.bin, else the path */
 } config;
@@ -96,7 +96,7 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i) {
     if (!theta || !mean || !sd || !ieuma || !tpm || !ir || !iri || !rounds) { rc = EMSAR_HOST_ERR_OOM; goto done; }
 
     /* ---- the replaced call: run_MLE_threads() + construct_FPKMfinal, emsar_main.c:444-450 ---- */
-    emsar_em_params p = {cfg->max_iter, cfg->accel, cfg->tol, 0.0, 0, cfg->set_mode, cfg->count_floor, cfg->zero_cut};
+    emsar_em_params p = {cfg->max_iter, cfg->accel, cfg->tol, 0.0, 0, cfg->set_mode, cfg->count_floor, cfg->zero_cut, cfg->abs_step};
     if ((rc = emsar_hip_upload_sample(ctx, cnt->R, m->E_solver, NULL)) ||
         (rc = emsar_hip_solve(ctx, &p, theta, &w->stats[i]))) {
         fprintf(stderr, "alnfile[%d]: %s (%s)\n", i, emsar_hip_strerror(rc), emsar_hip_last_error(ctx));
@@ -168,6 +168,7 @@ static void usage(const char *a0) {
             "      --count-floor <reads> stopping-rule floor in inferred reads (default 0 = off; e.g. 1e-3 for large samples)\n"
             "      --zero-cut <x>        components below x and still falling do not hold the solve up (default 2.5e-7: they print as\n"
             "                            0.000000 either way; 0 = every component must meet -e)\n"
+            "      --abs-step <x>        components that move by less than x FPKM per pass count as converged (default 1e-13; 0 = off)\n"
             "      --rsh-cache[=file]    read the parsed index from a binary cache (default <rshfile>.bin), write it after a text parse\n"
             "      --streaming-only      do not split the problem into connected sets (every pass streams the whole matrix)\n"
             "      --gpus <n> / --device <d> / --plain / --stats-json <file> / -q / -v\n", a0);
@@ -177,6 +178,7 @@ int main(int argc, char **argv) {
     config cfg; memset(&cfg, 0, sizeof cfg);
     cfg.ao.max_repeat = 100; cfg.n_round = 4; cfg.verbose = 1; cfg.accel = 1; cfg.tol = 1e-10; cfg.max_iter = 200000;
     cfg.zero_cut = 2.5e-7;      /* a quarter of the "%lf" print quantum of the .fpkm file */
+    cfg.abs_step = 1e-13;       /* see emsar_em_params.abs_step */
     const char *strand = "ns"; int multisample = 0, gpus = 0, device = 0;
     static struct option lo[] = {
         {"rsh", required_argument, 0, 'I'}, {"PE", no_argument, 0, 'P'}, {"strand_type", required_argument, 0, 's'},
@@ -185,7 +187,7 @@ int main(int argc, char **argv) {
         {"print_segments", no_argument, 0, 'g'}, {"multisample", no_argument, 0, 'M'}, {"SAM", no_argument, 0, 'S'}, {"BAM", no_argument, 0, 'B'},
         {"verbose", no_argument, 0, 'v'}, {"no_verbose", no_argument, 0, 'q'}, {"gpus", required_argument, 0, 1000},
         {"device", required_argument, 0, 1001}, {"plain", no_argument, 0, 1002}, {"stats-json", required_argument, 0, 1003},
-        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005}, {"rsh-cache", optional_argument, 0, 1006}, {"zero-cut", required_argument, 0, 1007},
+        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005}, {"rsh-cache", optional_argument, 0, 1006}, {"zero-cut", required_argument, 0, 1007}, {"abs-step", required_argument, 0, 1008},
         {"maxfraglen", required_argument, 0, 'F'}, {"minfraglen", required_argument, 0, 'f'}, {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "vqPs:p:F:f:n:e:d:gMSBk:i:I:", lo, NULL)) != -1) {
@@ -214,6 +216,7 @@ int main(int argc, char **argv) {
             case 1005: cfg.set_mode = 1; break;
             case 1006: cfg.rsh_cache = optarg ? optarg : ""; break;
             case 1007: cfg.zero_cut = atof(optarg); break;
+            case 1008: cfg.abs_step = atof(optarg); break;
             default: usage(argv[0]); return 1;
         }
     }

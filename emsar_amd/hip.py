@@ -30,7 +30,7 @@ class EmsarHipError(RuntimeError):
 
 class EmParams(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("accel", C.c_int32), ("tol", C.c_double), ("abs_floor", C.c_double),
-                ("check_every", C.c_int32), ("set_mode", C.c_int32), ("count_floor", C.c_double), ("zero_cut", C.c_double)]
+                ("check_every", C.c_int32), ("set_mode", C.c_int32), ("count_floor", C.c_double), ("zero_cut", C.c_double), ("abs_step", C.c_double)]
 
 
 class EmStats(C.Structure):
@@ -205,9 +205,9 @@ class EmsarHip:
         self._chk(self._L.emsar_hip_upload_sample(self._h, _p(w, C.c_int32), _p(e, C.c_double), _p(d, C.c_double)),
                   "upload_sample")
 
-    def solve(self, max_iter=100000, accel=1, tol=1e-10, abs_floor=1e-6, check_every=8, count_floor=0.0, set_mode=0, zero_cut=0.0):
+    def solve(self, max_iter=100000, accel=1, tol=1e-10, abs_floor=1e-6, check_every=8, count_floor=0.0, set_mode=0, zero_cut=0.0, abs_step=0.0):
         """set_mode 0: connected sets that fit a CU's LDS are solved by one workgroup each; 1: streaming passes only."""
-        p = EmParams(max_iter, accel, tol, abs_floor, check_every, set_mode, count_floor, zero_cut)
+        p = EmParams(max_iter, accel, tol, abs_floor, check_every, set_mode, count_floor, zero_cut, abs_step)
         st = EmStats()
         out = np.zeros(self.n_tx)
         self._chk(self._L.emsar_hip_solve(self._h, C.byref(p), _p(out, C.c_double), C.byref(st)), "solve")

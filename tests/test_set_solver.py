@@ -107,14 +107,14 @@ def test_max_iter_is_reported(dev, golden):
 
 
 @pytest.mark.parametrize("set_mode", [0, 1])
-def test_zero_cut_stops_earlier_and_prints_the_same(dev, golden, set_mode):
-    """emsar_em_params.zero_cut: components below a quarter of the .fpkm print quantum that are still falling no longer
-    hold the solve up.  Fewer passes, the reference parity criterion still met, nothing moves by more than the quantum."""
+def test_print_quantum_stopping_rules(dev, golden, set_mode):
+    """emsar_em_params.zero_cut / abs_step: components below a quarter of the .fpkm print quantum that are still falling,
+    or that move by less than 1e-13 FPKM per pass, no longer hold the solve up.  Fewer passes, the reference parity criterion still met, nothing moves by more than the quantum."""
     m = golden.model
     dev.upload_structure(m.n_tx, m.row_ptr, m.col_idx, LAYOUT_TILED)
     dev.upload_sample(m.R, m.E, None)
     strict, st_s = dev.solve(max_iter=600000, tol=1e-10, set_mode=set_mode)
-    quick, st_q = dev.solve(max_iter=600000, tol=1e-10, set_mode=set_mode, zero_cut=2.5e-7)
+    quick, st_q = dev.solve(max_iter=600000, tol=1e-10, set_mode=set_mode, zero_cut=2.5e-7, abs_step=1e-13)
     assert st_q.converged == 1
     if set_mode == 0:                     # resident sets follow the same trajectory up to the stop (no atomics); the streaming
         assert st_q.iters <= st_s.iters   # solve's pass counts vary from run to run
