@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
             double dd = fabs(y - x) / (fabs(y) + fl);
             if (!(dd == dd)) dd = __builtin_huge_val();
             if (y < P.zero_cut && y <= x) dd = 0.0;
-            if (fabs(y - x) < P.abs_step) dd = 0.0;
+            if (fabs(y - x) * (double)(passes + 1 > 1000 ? passes + 1 : 1000) < P.abs_step * 2e5) dd = 0.0;   // projected drift, see emsar_em_params.abs_step
             dloc = fmax(dloc, dd);
         }
         delta = set_reduce_max<THREADS>(dloc, L.red);
@@ -1810,7 +1810,8 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     if (p.set_mode != 0 && p.set_mode != 1) return EMSAR_HIP_ERR_ARG;
     ctx->count_floor = p.count_floor;
     ctx->zero_cut = p.zero_cut > 0.0 ? p.zero_cut : 0.0;
-    ctx->abs_step = p.abs_step > 0.0 ? p.abs_step : 0.0;
+    const double abs_step_base = p.abs_step > 0.0 ? p.abs_step : 0.0;
+    ctx->abs_step = abs_step_base * 200.0;            // pass-dependent, set before every cycle below (bound at pass <= 1000)
     ctx->delta_mask = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
     int rc;
@@ -1830,6 +1831,7 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     double delta = need_stream ? INFINITY : 0.0;
     while (need_stream && iters < p.max_iter) {
         hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
+        ctx->abs_step = abs_step_base * 2e5 / (double)std::max(iters + 1, 1000);      // projected drift bound, emsar_em_params.abs_step
         if (!p.accel) {
             if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor))) return rc;
             std::swap(th[0], th[1]);

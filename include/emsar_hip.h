@@ -75,11 +75,12 @@ typedef struct {
                              0.000000, so with zero_cut = 2.5e-7 the .fpkm file is the same while the 1/k decay of boundary
                              components (optimum theta = 0 with zero gradient) stops costing tens of thousands of passes.
                              <= 0 = off (every component must meet tol). */
-    double  abs_step;     /* > 0: a component whose change in one plain EM step is below this (in FPKM) counts as converged
-                             whatever its relative change.  Nearly flat directions converge sublinearly (|dtheta_k| ~ k^-p,
-                             p >= 2): what is left after stopping at |dtheta| < a in pass K is at most ~a*K, so 1e-13
-                             bounds it by 2e-8 FPKM at K = 200 000 -- a fiftieth of the .fpkm print quantum -- while the
-                             relative rule at 1e-10 keeps such components going for 10^5 passes.  <= 0 = off. */
+    double  abs_step;     /* > 0: a component counts as converged, whatever its relative change, once its change in one plain
+                             EM step (in FPKM) is below abs_step * 200000 / K at pass K (K >= 1000).  Nearly flat directions
+                             converge sublinearly (|dtheta_k| ~ k^-p, p >= 2): what is left after stopping at |dtheta| < a in
+                             pass K is at most ~a*K, so the rule bounds the remaining drift by abs_step * 2e5 at every K --
+                             2e-8 FPKM, a fiftieth of the .fpkm print quantum, for 1e-13 -- while the relative rule at 1e-10
+                             keeps such components going for 10^5 passes.  <= 0 = off. */
 } emsar_em_params;
 
 typedef struct {
