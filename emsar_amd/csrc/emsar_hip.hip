@@ -917,10 +917,44 @@ __global__ __launch_bounds__(256) void k_update_p3(int n, const double *__restri
 struct SetStat { int32_t passes, converged; double delta; };
 struct SetSolveParams { double tol, abs_floor, count_floor, zero_cut, abs_step; int32_t max_iter, accel; };
 
+// Wave-wide reductions on the DPP path (row shifts inside rows of 16 lanes, then row broadcasts; the total lands in lane
+// 63 and is read back as a scalar): ~6 cross-lane moves per value instead of the twelve ds_bpermute round trips of a
+// shuffle butterfly.  The per-set solver is a chain of dependent steps, so the latency of its reductions is pass time.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v, double identity) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v), id = (unsigned long long)__double_as_longlong(identity);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)id, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(id >> 32), (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double wave_bcast63(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_move<0x111>(v, 0.0);      // row_shr:1
+    v += dpp_move<0x112>(v, 0.0);      // row_shr:2
+    v += dpp_move<0x114>(v, 0.0);      // row_shr:4
+    v += dpp_move<0x118>(v, 0.0);      // row_shr:8   -> lane 15 of every row holds its row's sum
+    v += dpp_move<0x142>(v, 0.0);      // row_bcast:15 -> lane 31 / 63 hold the sums of rows 0-1 / 2-3 (plus their own rows)
+    v += dpp_move<0x143>(v, 0.0);      // row_bcast:31 -> lane 63 holds the wave's sum
+    return wave_bcast63(v);
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {      // v >= 0
+    v = fmax(v, dpp_move<0x111>(v, 0.0));
+    v = fmax(v, dpp_move<0x112>(v, 0.0));
+    v = fmax(v, dpp_move<0x114>(v, 0.0));
+    v = fmax(v, dpp_move<0x118>(v, 0.0));
+    v = fmax(v, dpp_move<0x142>(v, 0.0));
+    v = fmax(v, dpp_move<0x143>(v, 0.0));
+    return wave_bcast63(v);
+}
+
 template <int THREADS, int N>
 __device__ __forceinline__ void set_reduce_sum(double (&v)[N], double *red) {
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] = wave_sum(v[i]);
+    for (int i = 0; i < N; i++) v[i] = wave_sum_dpp(v[i]);
     if (THREADS > 64) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         __syncthreads();                       // red may still be read from the previous reduction
@@ -938,7 +972,7 @@ __device__ __forceinline__ void set_reduce_sum(double (&v)[N], double *red) {
 }
 template <int THREADS>
 __device__ __forceinline__ double set_reduce_max(double v, double *red) {
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    v = wave_max_dpp(v);
     if (THREADS > 64) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         __syncthreads();
@@ -949,6 +983,17 @@ __device__ __forceinline__ double set_reduce_max(double v, double *red) {
         v = t;
     }
     return v;
+}
+
+// 1/x for normal positive x: v_rcp_f64 (about half the mantissa) refined by two Newton steps -- five dependent
+// instructions instead of the dozen of the IEEE division sequence (scaling, fix-up).  The per-set solver is a chain of
+// dependent steps; theta, den and the row sums it divides by are far from the exponent range where the fix-ups matter.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
 }
 
 struct SetLds {
@@ -965,15 +1010,15 @@ __device__ __forceinline__ double set_em_estep(const SetLds &L, const double *x)
     for (int j = threadIdx.x; j < L.nr; j += THREADS) {
         double S = 0.0;
         const int b = L.rp[j], e = L.rp[j + 1];
-        int k = b;
-        for (; k + 4 <= e; k += 4) {      // four independent index -> value chains in flight
-            const int i0 = L.ent[k], i1 = L.ent[k + 1], i2 = L.ent[k + 2], i3 = L.ent[k + 3];
-            S += (x[i0] + x[i1]) + (x[i2] + x[i3]);
+        for (int k = b; k < e; k += 4) {  // four independent index -> value chains in flight, also for the last 1..3 entries
+            const int l = e - 1;
+            const int i0 = L.ent[k], i1 = L.ent[k + 1 < e ? k + 1 : l], i2 = L.ent[k + 2 < e ? k + 2 : l], i3 = L.ent[k + 3 < e ? k + 3 : l];
+            const double v0 = x[i0], v1 = x[i1], v2 = x[i2], v3 = x[i3];
+            S += (v0 + (k + 1 < e ? v1 : 0.0)) + ((k + 2 < e ? v2 : 0.0) + (k + 3 < e ? v3 : 0.0));
         }
-        for (; k < e; k++) S += x[L.ent[k]];
         const double r = L.rw[j];
         const bool live = S > 0.0;
-        L.w[j] = live ? r / S : 0.0;
+        L.w[j] = live ? r * fast_rcp(S) : 0.0;
         if (LL && live) ll += r * log(S);
     }
     __syncthreads();
@@ -982,16 +1027,16 @@ __device__ __forceinline__ double set_em_estep(const SetLds &L, const double *x)
 __device__ __forceinline__ double set_em_acc(const SetLds &L, int i) {
     double a = 0.0;
     const int b = L.cp[i], e = L.cp[i + 1];
-    int k = b;
-    for (; k + 4 <= e; k += 4) {
-        const int j0 = L.crow[k], j1 = L.crow[k + 1], j2 = L.crow[k + 2], j3 = L.crow[k + 3];
-        a += (L.w[j0] + L.w[j1]) + (L.w[j2] + L.w[j3]);
+    for (int k = b; k < e; k += 4) {
+        const int l = e - 1;
+        const int j0 = L.crow[k], j1 = L.crow[k + 1 < e ? k + 1 : l], j2 = L.crow[k + 2 < e ? k + 2 : l], j3 = L.crow[k + 3 < e ? k + 3 : l];
+        const double v0 = L.w[j0], v1 = L.w[j1], v2 = L.w[j2], v3 = L.w[j3];
+        a += (v0 + (k + 1 < e ? v1 : 0.0)) + ((k + 2 < e ? v2 : 0.0) + (k + 3 < e ? v3 : 0.0));
     }
-    for (; k < e; k++) a += L.w[L.crow[k]];
     return a;
 }
 __device__ __forceinline__ double set_em_update(double x, double a, double u, double dn) {
-    return dn > 0.0 ? (x > 0.0 ? (x * a + u) / dn : 0.0) : 0.0;
+    return dn > 0.0 ? (x > 0.0 ? (x * a + u) * fast_rcp(dn) : 0.0) : 0.0;
 }
 
 template <int THREADS>
@@ -1033,7 +1078,7 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
             B[i] = y;
             double fl = P.abs_floor;
             if (P.count_floor > 0.0 && dn > 0.0) fl = fmax(fl, P.count_floor / dn);
-            double dd = fabs(y - x) / (fabs(y) + fl);
+            double dd = fabs(y - x) * fast_rcp(fabs(y) + fl);
             if (!(dd == dd)) dd = __builtin_huge_val();
             if (y < P.zero_cut && y <= x) dd = 0.0;
             if (fabs(y - x) * (double)(passes + 1 > 1000 ? passes + 1 : 1000) < P.abs_step * 2e5) dd = 0.0;   // projected drift, see emsar_em_params.abs_step

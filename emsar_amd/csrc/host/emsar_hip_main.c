@@ -58,7 +58,7 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i) {
     config *cfg = w->cfg; const emsar_rsh *r = w->rsh;
     char err[512] = "", path[4096];
     emsar_counts *cnt = NULL; emsar_model *m = NULL;
-    double *theta = NULL, *rounds = NULL, *mean = NULL, *sd = NULL, *ieuma = NULL, *tpm = NULL, *ir = NULL; int32_t *iri = NULL;
+    double *theta = NULL, *rounds = NULL, *mean = NULL, *sd = NULL, *ieuma = NULL, *tpm = NULL, *ir = NULL, *den = NULL; int32_t *iri = NULL;
     int rc;
     double t0 = now_s();
     rc = emsar_count_alignments(r, cfg->aln[i], &cfg->ao, &cnt, err, sizeof err);
@@ -97,7 +97,15 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i) {
 
     /* ---- the replaced call: run_MLE_threads() + construct_FPKMfinal, emsar_main.c:444-450 ---- */
     emsar_em_params p = {cfg->max_iter, cfg->accel, cfg->tol, 0.0, 0, cfg->set_mode, cfg->count_floor, cfg->zero_cut, cfg->abs_step};
-    if ((rc = emsar_hip_upload_sample(ctx, cnt->R, m->E_solver, NULL)) ||
+    /* den_t = sum_c m_ct E_c in row order on the host: the device's own scatter adds with atomics, whose order (and with it
+     * the last bits of den, of theta and now and then the sixth printed decimal) changes from run to run */
+    den = (double *)calloc(T, sizeof(double));
+    if (!den) { rc = EMSAR_HOST_ERR_OOM; goto done; }
+    for (int64_t c = 0; c < r->n_rows; c++) {
+        const double e = m->E_solver[c];
+        if (e != 0.0) for (uint64_t k = r->row_ptr[c]; k < r->row_ptr[c + 1]; k++) den[r->col_idx[k]] += e;
+    }
+    if ((rc = emsar_hip_upload_sample(ctx, cnt->R, m->E_solver, den)) ||
         (rc = emsar_hip_solve(ctx, &p, theta, &w->stats[i]))) {
         fprintf(stderr, "alnfile[%d]: %s (%s)\n", i, emsar_hip_strerror(rc), emsar_hip_last_error(ctx));
         goto done;
@@ -124,7 +132,7 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i) {
         fprintf(stdout, "Complete: %s/%s.%d.fpkm  (EM passes %d, converged %d, solve %.1f ms, logL %.6f)\n", cfg->outdir, cfg->prefix, i,
                 w->stats[i].iters, w->stats[i].converged, w->stats[i].solve_ms, w->stats[i].loglik);
 done:
-    free(theta); free(rounds); free(mean); free(sd); free(ieuma); free(tpm); free(ir); free(iri);
+    free(theta); free(rounds); free(mean); free(sd); free(ieuma); free(tpm); free(ir); free(iri); free(den);
     emsar_counts_free(cnt); emsar_model_free(m);
     return rc;
 }
