@@ -201,6 +201,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 900) block = v; }
     int64_t tile_rows = kTileRows;
     if (const char *e = getenv("EMSAR_HIP_TILE_ROWS")) { int v = atoi(e); if (v >= kTileSliceRows && v <= kTileRows) tile_rows = v / kTileSliceRows * kTileSliceRows; }
+    int dense_min = kDenseMin;
+    if (const char *e = getenv("EMSAR_HIP_TILE_DENSE")) { int v = atoi(e); if (v >= 1 && v <= 64) dense_min = v; }
     bool cut_at_slices = true;
     if (const char *e = getenv("EMSAR_HIP_TILE_CUT")) cut_at_slices = atoi(e) != 0;
     // ---- sort: pass A by anchor tid, pass B by (block, length class); both stable ----
@@ -352,7 +354,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 size_t coo_before = out.coo.size();
                 for (int d = 0; d < nd; d++) {
                     uint32_t b = ccount[(size_t)d], e = ccount[(size_t)d + 1];
-                    if (e - b < (uint32_t)kDenseMin) {
+                    if (e - b < (uint32_t)dense_min) {
                         for (uint32_t q = b; q < e; q++) out.coo.push_back(((uint32_t)d << 16) | (sorted[q] & 0xFFFF));
                         continue;
                     }
