@@ -68,7 +68,10 @@ __device__ bool same_multiset(const int32_t *x, const int32_t *y, uint64_t n) {
 // rows; what limits the kernel is the rate at which ONE L2 line can be served.  Measured on 10M rows (config 3 x 0.2):
 // claim word, first occurrence and count in three arrays 4.1 ms; all of a segment's state packed into one 64-byte
 // slot 19.8 ms (every load and atomic of a hot segment queues on the same line); counts and first occurrences
-// pre-combined per workgroup in LDS with 8 rows per thread 7 ms (the probe chains of a thread run one after another).
+// pre-combined per workgroup in LDS with 8 rows per thread 7 ms (the probe chains of a thread run one after another);
+// one leader per distinct row of a 1024-row workgroup elected in an LDS table, only leaders probing the global table
+// 4.8 ms (total 6.2 against 5.6): duplicates inside a workgroup are too few, the cost is the ~8 random lines EVERY row
+// touches (table word, the representative's two hashes, its row_ptr pair, its ids, first, count).
 __global__ __launch_bounds__(256) void k_row_insert(int64_t n_rows, const uint64_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                     const int32_t *__restrict__ wgt, const uint64_t *__restrict__ h1, const uint64_t *__restrict__ h2,
                                                     unsigned long long *__restrict__ table, uint64_t mask, int32_t *__restrict__ slot_of,
