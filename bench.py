@@ -108,8 +108,9 @@ def main():
     out = None
     if rank == 0:
         per_pass_s = kernel_ms / 1e3 / args.steps
-        # unweighted TILED passes run two tiles per workgroup unless EMSAR_HIP_TILED_MULTI=0 (emsar_hip.hip, launch_pass)
-        tiled_kernel = "k_pass_tiled" if os.environ.get("EMSAR_HIP_TILED_MULTI", "2") in ("0", "1") else "k_pass_tiled_multi<2>"
+        # unweighted TILED passes run two tiles per workgroup above 2048 tiles (emsar_hip.hip, launch_pass; EMSAR_HIP_TILED_MULTI 0/2 force)
+        knob = os.environ.get("EMSAR_HIP_TILED_MULTI", "1")
+        tiled_kernel = "k_pass_tiled_multi<2>" if knob == "2" or (knob == "1" and info["n_chunks"] > 2048) else "k_pass_tiled"
         bytes_pass = info["bytes_per_pass"]
         achieved = bytes_pass / per_pass_s / 1e9
         out = {

@@ -49,6 +49,8 @@ struct Scal {
     unsigned long long delta1_bits; // the same, frozen after the first (plain) pass of a SQUAREM cycle
     int32_t accepted, rejected;
     double sum_a, sum_b;          // generic reductions (normalise)
+    long long passes;             // EM passes enqueued before the current cycle (k_cycle_begin keeps it: the cycle may replay from a hipGraph)
+    double abs_step_cur;          // emsar_em_params.abs_step scaled to the pass count of the current cycle (0 = rule off)
 };
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
@@ -785,11 +787,12 @@ __global__ void k_fill_start(int n, const double *__restrict__ den, double *__re
 // grid-stride, one atomicMax per workgroup (hundreds of same-address atomics cost ~12 ns each)
 __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
                                                 const double *__restrict__ den, const double *__restrict__ u /* folded single-tid rows, may be null */,
-                                                double *__restrict__ th_out, double abs_floor, double count_floor, double zero_cut, double abs_step, Scal *scal,
+                                                double *__restrict__ th_out, double abs_floor, double count_floor, double zero_cut, Scal *scal,
                                                 const uint8_t *__restrict__ kind /* non-null: only KIND_STREAMED transcripts enter the stopping rule */,
                                                 int to_delta1 /* the first (plain) step of a SQUAREM cycle: the cycle's stopping rule */) {
     __shared__ double red[4];
     double d = 0.0;
+    const double abs_step = scal->abs_step_cur;      // written by k_cycle_begin, nobody writes it during a pass
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
         double a = acc[t], dn = den[t], x = th_in[t];
         // a row {t} contributes R/theta_t to acc_t, i.e. R to theta_t*acc_t: added analytically (TILED layout)
@@ -817,13 +820,19 @@ __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict_
     }
 }
 
-__global__ void k_cycle_begin(Scal *s) {
+// abs_step_base > 0: the projected-drift bound of emsar_em_params.abs_step, |dtheta| < base * 2e5 / K at pass K >= 1000.  K is
+// counted here, on the device, so that a cycle recorded once in a hipGraph carries the right bound at every replay.
+__global__ void k_cycle_begin(Scal *s, double abs_step_base, int passes_in_cycle) {
     s->ll[0] = s->ll[1] = s->ll[2] = s->ll[3] = 0.0;
     s->sr2 = s->sv2 = s->pen1 = s->penx = 0.0;
     s->delta_bits = 0ull; s->delta1_bits = 0ull;
+    const long long done = s->passes;
+    s->abs_step_cur = abs_step_base > 0.0 ? abs_step_base * 2e5 / (double)(done + 1 > 1000 ? done + 1 : 1000) : 0.0;
+    s->passes = done + passes_in_cycle;
 }
 __global__ void k_scal_init(Scal *s) {
     s->stepmax = 1.0; s->s_used = 1.0; s->accepted = 0; s->rejected = 0; s->sum_a = s->sum_b = 0.0;
+    s->passes = 0; s->abs_step_cur = 0.0;
 }
 
 // ---- the SQUAREM cycle of the streaming solve with the O(T) work folded into the three update kernels ----
@@ -1225,6 +1234,8 @@ __global__ void k_normalise(int n, const double *__restrict__ mean, const double
 // ==================================================================================================
 // context
 // ==================================================================================================
+constexpr int64_t kPairMinTiles = 2048;   // 256 CUs x 4 resident workgroups x 2 tiles
+
 struct emsar_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1269,9 +1280,12 @@ struct emsar_hip_ctx {
     int64_t bytes_formula = 0, bytes_stored = 0;
     int64_t tl_fwd_slots = 0, tl_n_fslices = 0;
     double count_floor = 0.0;    // stopping-rule floor in reads for the current solve (emsar_em_params.count_floor)
-    double zero_cut = 0.0, abs_step = 0.0;   // emsar_em_params.zero_cut / abs_step of the current solve
+    double zero_cut = 0.0;       // emsar_em_params.zero_cut of the current solve
+    bool use_graph = true;       // replay check_every cycles of the streaming solve from one hipGraph (EMSAR_HIP_GRAPH=0: launch each kernel)
+    int64_t graph_launches = 0;  // of the last solve (debug: EMSAR_HIP_DEBUG)
     int update_grid = 256;       // workgroups of k_update (EMSAR_HIP_UPDATE_GRID)
-    int tiled_multi = 2;         // 2: two tiles per workgroup, software-pipelined (k_pass_tiled_multi); 0: one (k_pass_tiled)
+    int tiled_multi = 1;         // EMSAR_HIP_TILED_MULTI 1: two tiles per workgroup (k_pass_tiled_multi) above kPairMinTiles tiles, else one
+                                 // (k_pass_tiled); 2: always two; 0: always one
     const uint8_t *delta_mask = nullptr;   // d_kind while the streaming solve runs next to resident sets
     // set-resident solver (sets.hpp): host copy of the CSR and of the sample's row weights, built lazily by solve
     std::vector<uint64_t> h_row_ptr;
@@ -1354,9 +1368,11 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
                        (int)ctx->n_tiles, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, theta, acc, ll_out)
 #define LAUNCH_P(WT, MD) LAUNCH_PN(WT, MD, 2)
             if (mode == MODE_SCATTER) LAUNCH_T(false, MODE_SCATTER);
-            else if (ctx->tiled_multi >= 2 && !ctx->weighted) {
+            else if (!ctx->weighted && (ctx->tiled_multi >= 2 || (ctx->tiled_multi == 1 && ctx->n_tiles > kPairMinTiles))) {
                 // two tiles per workgroup, software-pipelined: +3 % on config 3.  Unweighted rows only: with the row
-                // weights in registers as well the two-tile body does not fit 128 VGPRs (0.218 vs 0.179 ms measured)
+                // weights in registers as well the two-tile body does not fit 128 VGPRs (0.218 vs 0.179 ms measured).
+                // Only when the tiles outnumber the chip's workgroup slots: below that a pass is one workgroup's latency, and
+                // a pair takes twice as long as a tile (40 k reads: 47 -> 26 us per pass with one tile per workgroup)
                 if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM);
             }
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
@@ -1416,11 +1432,48 @@ int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_l
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot]);
     if (rc) return rc;
     hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), ctx->update_grid)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
-                       ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->zero_cut, ctx->abs_step, ctx->d_scal,
+                       ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->zero_cut, ctx->d_scal,
                        ctx->delta_mask, to_delta1);
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
 }
+
+// `cycles` cycles of the streaming solve on ctx->stream -- launched, or recorded when the stream is capturing.
+// One cycle = one plain EM pass, or one SQUAREM cycle of three passes (8 launches, see k_update_p2).  The current point is
+// ctx->d_th[0] before and after (plain EM swaps d_th[0]/d_th[1] on the host: record an even count).
+int enqueue_cycles(emsar_hip_ctx *ctx, const emsar_em_params &p, double abs_step_base, int cycles) {
+    const int n = ctx->n_tx, g = grid_for(n, 256);
+    double **th = ctx->d_th;
+    int rc;
+    for (int c = 0; c < cycles; c++) {
+        hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal, abs_step_base, p.accel ? 3 : 1);
+        if (!p.accel) {
+            if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor))) return rc;
+            std::swap(th[0], th[1]);
+            continue;
+        }
+        // the stopping rule is measured on the first (plain) step of the cycle only (delta1_bits)
+        const double *u = ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr;
+        const dim3 gv((unsigned)std::min(g, 256)), bv(256);
+        if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor, 1))) return rc;
+        if ((rc = launch_pass(ctx, MODE_EM_LL, th[1], ctx->d_acc, &ctx->d_scal->ll[1], true))) return rc;
+        hipLaunchKernelGGL(k_update_p2, gv, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal);
+        hipLaunchKernelGGL(k_sq_extrap_ll, gv, bv, 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, u, th[3], ctx->d_scal);
+        if ((rc = launch_pass(ctx, MODE_EM_LL, th[3], ctx->d_acc, &ctx->d_scal->ll[2], true))) return rc;
+        hipLaunchKernelGGL(k_update_p3, gv, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal);
+        HIPCHK(hipGetLastError());
+    }
+    return EMSAR_HIP_OK;
+}
+
+struct CycleGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    ~CycleGraph() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+};
 
 // scatter a per-row value (original row order, host) to its columns: out[t] = sum_c m_ct val[c]
 int scatter_rows(emsar_hip_ctx *ctx, const double *val_host, double *d_out) {
@@ -1563,6 +1616,7 @@ int emsar_hip_create(emsar_hip_ctx **out, int device_id) {
     ctx->device = device_id;
     auto fail = [&](int rc) { emsar_hip_destroy(ctx); return rc; };
     if (hipSetDevice(device_id) != hipSuccess) return fail(EMSAR_HIP_ERR_NO_DEVICE);
+    if (const char *e = getenv("EMSAR_HIP_GRAPH")) ctx->use_graph = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipMalloc(&ctx->d_scal, sizeof(Scal)) != hipSuccess) return fail(EMSAR_HIP_ERR_OOM);
@@ -1638,7 +1692,7 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
 #define SETLDS_P(WT, MD, NN) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_multi<WT, MD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             SETLDS_P(false, MODE_EM, 2); SETLDS_P(false, MODE_EM_LL, 2);
 #undef SETLDS_P
-            { const char *pe = getenv("EMSAR_HIP_TILED_MULTI"); ctx->tiled_multi = pe ? atoi(pe) : 2; }
+            { const char *pe = getenv("EMSAR_HIP_TILED_MULTI"); ctx->tiled_multi = pe ? atoi(pe) : 1; }
             { const char *pe = getenv("EMSAR_HIP_UPDATE_GRID"); if (pe && atoi(pe) >= 1) ctx->update_grid = atoi(pe); }
         } else if (layout == EMSAR_LAYOUT_WINDOWED) {
             const char *wenv = getenv("EMSAR_HIP_WINDOW");
@@ -1825,7 +1879,7 @@ int emsar_hip_run_passes(emsar_hip_ctx *ctx, int32_t n_passes, float *elapsed_ms
     if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
     HIPCHK(hipSetDevice(ctx->device));
     ctx->delta_mask = nullptr;
-    hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
+    hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal, 0.0, 0);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int cur = 0;  // th[cur] holds the current point, th[cur^1] receives the next
     for (int i = 0; i < n_passes; i++) {
@@ -1856,7 +1910,6 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     ctx->count_floor = p.count_floor;
     ctx->zero_cut = p.zero_cut > 0.0 ? p.zero_cut : 0.0;
     const double abs_step_base = p.abs_step > 0.0 ? p.abs_step : 0.0;
-    ctx->abs_step = abs_step_base * 200.0;            // pass-dependent, set before every cycle below (bound at pass <= 1000)
     ctx->delta_mask = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
     int rc;
@@ -1871,30 +1924,35 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const int n = ctx->n_tx, g = grid_for(n, 256);
-    double **th = ctx->d_th;  // 0:th0 1:th1 2:th2 3:thx 4:thn
+    double **th = ctx->d_th;  // 0:th0 1:th1 2:th2 3:thx 4:thn (enqueue_cycles leaves the current point in th[0])
     int iters = 0, converged = need_stream ? 0 : 1, cycles = 0;
     double delta = need_stream ? INFINITY : 0.0;
+    // The first 4 x check_every cycles are launched kernel by kernel (a quick solve never pays for a graph); after that
+    // check_every cycles are recorded once into a hipGraph and replayed between the host's looks at the stopping rule.
+    // Measured gain: 1-5 % on problems of 40 k .. 2 M rows (tools/graph_bench.py) -- the launches were already asynchronous,
+    // and a pass of a small problem costs one workgroup's latency (12-26 us), not its launch.
+    const int per_cycle = p.accel ? 3 : 1;
+    const bool graph_ok = ctx->use_graph && (p.accel || p.check_every % 2 == 0);   // plain EM swaps th0/th1: an even count restores them
+    CycleGraph G;
+    ctx->graph_launches = 0;
     while (need_stream && iters < p.max_iter) {
-        hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
-        ctx->abs_step = abs_step_base * 2e5 / (double)std::max(iters + 1, 1000);      // projected drift bound, emsar_em_params.abs_step
-        if (!p.accel) {
-            if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor))) return rc;
-            std::swap(th[0], th[1]);
-            iters += 1;
-        } else {
-            // the stopping rule is measured on the first (plain) step of the cycle only (delta1_bits)
-            const double *u = ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr;
-            const dim3 gv((unsigned)std::min(g, 256)), bv(256);
-            if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor, 1))) return rc;
-            if ((rc = launch_pass(ctx, MODE_EM_LL, th[1], ctx->d_acc, &ctx->d_scal->ll[1], true))) return rc;
-            hipLaunchKernelGGL(k_update_p2, gv, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal);
-            hipLaunchKernelGGL(k_sq_extrap_ll, gv, bv, 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, u, th[3], ctx->d_scal);
-            if ((rc = launch_pass(ctx, MODE_EM_LL, th[3], ctx->d_acc, &ctx->d_scal->ll[2], true))) return rc;
-            hipLaunchKernelGGL(k_update_p3, gv, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal);
-            HIPCHK(hipGetLastError());
-            iters += 3;
-        }
-        cycles++;
+        int todo = 1;
+        if (graph_ok && cycles >= 4 * p.check_every && cycles % p.check_every == 0 &&
+            (int64_t)iters + (int64_t)per_cycle * p.check_every <= (int64_t)p.max_iter) {
+            todo = p.check_every;
+            if (!G.exec) {
+                HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                rc = enqueue_cycles(ctx, p, abs_step_base, todo);
+                hipError_t e = hipStreamEndCapture(ctx->stream, &G.graph);      // always closes the capture
+                if (rc) return rc;
+                HIPCHK(e);
+                HIPCHK(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
+            }
+            HIPCHK(hipGraphLaunch(G.exec, ctx->stream));
+            ctx->graph_launches++;
+        } else if ((rc = enqueue_cycles(ctx, p, abs_step_base, 1))) return rc;
+        cycles += todo;
+        iters += todo * per_cycle;
         if (cycles % p.check_every == 0 || iters >= p.max_iter) {
             HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1914,14 +1972,16 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     }
     HIPCHK(hipEventRecord(ctx->ev2, ctx->stream));
     // F at the returned point: one likelihood-only pass (not counted in iters)
-    hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal);
+    hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal, 0.0, 0);
     if ((rc = launch_pass(ctx, MODE_EM_LL, th[0], ctx->d_acc, &ctx->d_scal->ll[0]))) return rc;
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)n * 8, ctx->stream));
     hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, ctx->stream, n, th[0], ctx->d_den, &ctx->d_scal->ll[3]);
     HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(fpkm_out, th[0], (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->count_floor = 0.0; ctx->zero_cut = 0.0; ctx->abs_step = 0.0;
+    ctx->count_floor = 0.0; ctx->zero_cut = 0.0;
+    if (getenv("EMSAR_HIP_DEBUG"))
+        fprintf(stderr, "emsar_hip_solve: %d streaming passes, %lld graph replays of %d cycles\n", iters, (long long)ctx->graph_launches, p.check_every);
     for (int32_t t = 0; t < n; t++)
         if (!std::isfinite(fpkm_out[t])) { ctx->err = "non-finite theta"; return EMSAR_HIP_ERR_NUMERIC; }
     int32_t set_max = 0, set_unconv = 0;

@@ -239,6 +239,34 @@ def test_full_size_properties_cfg2(dev):
         assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
 
 
+def test_tiled_pair_and_single_kernels_match_oracle(monkeypatch):
+    """Unweighted TILED passes run two tiles per workgroup (k_pass_tiled_multi) only when the tiles outnumber the chip's
+    workgroup slots, one (k_pass_tiled) below that; the knob forces either kernel on a matrix of a few dozen tiles.  The
+    solve is long enough for the hipGraph replay of the SQUAREM cycle to start (4 x check_every cycles in)."""
+    s = synth.make_config("cfg3", 0.004)
+    m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
+    want = np.ones(s["n_tx"])
+    for _ in range(3):
+        want, _ = m.em_step(want, s["den"], n_threads=4)
+    F = {}
+    for multi, graph in (("0", "1"), ("2", "1"), ("2", "0")):
+        monkeypatch.setenv("EMSAR_HIP_TILED_MULTI", multi)
+        monkeypatch.setenv("EMSAR_HIP_GRAPH", graph)
+        with EmsarHip(0) as ctx:
+            ctx.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
+            ctx.upload_sample(None, None, s["den"])
+            assert ctx.info()["n_chunks"] > 3
+            ctx.run_passes(3)
+            got = ctx.get_theta()
+            assert np.all(np.abs(got - want) <= 1e-11 * np.abs(want) + 1e-300)
+            th, st = ctx.solve(max_iter=3000, accel=1, tol=1e-9, set_mode=1)
+            assert st.iters > 4 * 8 * 3 and (st.converged == 1 or st.iters >= 2990)
+            assert abs((th * s["den"]).sum() - s["n_reads"]) < 1e-9 * s["n_reads"]       # the EM map conserves the read mass
+            F[(multi, graph)] = st.loglik
+    ref = F[("0", "1")]
+    assert all(abs(v - ref) <= 1e-8 * abs(ref) for v in F.values()), F
+
+
 def test_csr_with_64bit_row_pointers(monkeypatch):
     """Config 5 at full size has nnz = 4e9, just under 2^32; above it the CSR kernels read 64-bit row pointers.  The
     test hook forces that code path on a small matrix: same pass, same solve."""
