@@ -40,7 +40,10 @@ typedef struct { char qname[1024]; char rname[1024]; char md[4096]; int flag, po
 
 /* ---- BAM: BGZF is a series of gzip members, which zlib's gzread() inflates transparently (SAM/BAM spec section 4).
  * The reference reads BAM through its vendored samtools 0.1.19 (bam.c, bgzf.c); only the fields above are used. ---- */
-typedef struct { gzFile f; struct emsar_pbgzf *pf; int n_ref; char **ref; int32_t *ref_tid; const emsar_rsh *rsh; unsigned char *buf; size_t cap; } bamreader;
+typedef struct {
+    gzFile f; struct emsar_pbgzf *pf; int n_ref; char **ref; int32_t *ref_tid; const emsar_rsh *rsh; unsigned char *buf; size_t cap;
+    const unsigned char *mem; size_t mem_n, mem_pos;   /* a worker's view: whole records already in memory (count_bam_parallel) */
+} bamreader;
 
 /* bytes delivered (short only at the end of the stream), -1 on error: the BGZF blocks of a regular file are inflated
  * by a pool of threads (pbgzf.c), anything else (stdin, plain gzip) by zlib on this thread */
@@ -91,15 +94,26 @@ static bamreader *bam_open(const char *path, const emsar_rsh *rsh) {
 
 /* returns 1 record read, 0 end of file, -1 malformed */
 static int bam_next(bamreader *b, samrec *r) {
-    unsigned char h[4];
-    long got = bam_get(b, h, 4);
-    if (got == 0) return 0;
-    if (got != 4) return -1;
-    int32_t bs = le32(h);
-    if (bs < 32 || bs > (1 << 28)) return -1;
-    if ((size_t)bs > b->cap) { unsigned char *nb = (unsigned char *)realloc(b->buf, (size_t)bs); if (!nb) return -1; b->buf = nb; b->cap = (size_t)bs; }
-    if (bam_rd(b, b->buf, (size_t)bs)) return -1;
-    const unsigned char *p = b->buf;
+    const unsigned char *p;
+    int32_t bs;
+    if (b->mem) {                                                     /* records of a batch, in place */
+        if (b->mem_pos == b->mem_n) return 0;
+        if (b->mem_n - b->mem_pos < 4) return -1;
+        bs = le32(b->mem + b->mem_pos);
+        if (bs < 32 || (size_t)bs > b->mem_n - b->mem_pos - 4) return -1;
+        p = b->mem + b->mem_pos + 4;
+        b->mem_pos += 4 + (size_t)bs;
+    } else {
+        unsigned char h[4];
+        long got = bam_get(b, h, 4);
+        if (got == 0) return 0;
+        if (got != 4) return -1;
+        bs = le32(h);
+        if (bs < 32 || bs > (1 << 28)) return -1;
+        if ((size_t)bs > b->cap) { unsigned char *nb = (unsigned char *)realloc(b->buf, (size_t)bs); if (!nb) return -1; b->buf = nb; b->cap = (size_t)bs; }
+        if (bam_rd(b, b->buf, (size_t)bs)) return -1;
+        p = b->buf;
+    }
     int32_t refid = le32(p), pos = le32(p + 4), l_seq = le32(p + 16);
     int l_name = p[8], n_cig = p[12] | (p[13] << 8), flag = p[14] | (p[15] << 8);
     size_t off = 32;
@@ -266,11 +280,25 @@ static int mate_id_len(const char *a, const char *b) {
  * records: a worker with begin > 0 skips the group of its first kept record (the worker on its left finishes that
  * group, wherever it started), and every worker stops at the first kept record that follows the group of the first
  * kept record at or after `end`.  *got_group = 0 when the range held no group at all. */
+static emsar_counts *counts_new(const emsar_rsh *r) {
+    emsar_counts *c = (emsar_counts *)calloc(1, sizeof(*c));
+    if (!c) return NULL;
+    c->n_rows = r->n_rows;
+    c->n_frag = r->hdr_maxfrag + 1;
+    c->R = (int32_t *)calloc((size_t)r->n_rows, sizeof(int32_t));
+    c->frag_counts = (int32_t *)calloc((size_t)c->n_frag, sizeof(int32_t));
+    c->readlength = r->hdr_readlength;
+    if (!c->R || !c->frag_counts) { emsar_counts_free(c); return NULL; }
+    return c;
+}
+
+/* mem_bam / acc (both or neither): the records of one batch of a BAM file, already in memory and starting on a read
+ * group, counted into the caller's accumulator (count_bam_parallel) */
 static int count_range(const emsar_rsh *r, const char *path, const emsar_aln_opts *o, int64_t begin, int64_t end,
-                       emsar_counts **out, int *got_group, char *err, size_t errlen) {
+                       emsar_counts **out, int *got_group, char *err, size_t errlen, bamreader *mem_bam, emsar_counts *acc) {
     int rc = EMSAR_HOST_OK;
     *out = NULL; *got_group = 0;
-    emsar_counts *c = (emsar_counts *)calloc(1, sizeof(*c));
+    emsar_counts *c = acc ? acc : counts_new(r);
     int skipping = begin > 0, end_seen = 0, pe_align = begin > 0;
     char *skip_id = NULL, *end_id = NULL;
     int64_t rec_off = 0;
@@ -280,14 +308,9 @@ static int count_range(const emsar_rsh *r, const char *path, const emsar_aln_opt
     int32_t *tmp = NULL; int tmpcap = 0;
     char *prev = NULL; size_t prevcap = 0;
     char *line2 = NULL;
-    if (!c) return EMSAR_HOST_ERR_OOM;
-    c->n_rows = r->n_rows;
-    c->n_frag = r->hdr_maxfrag + 1;
-    c->R = (int32_t *)calloc((size_t)r->n_rows, sizeof(int32_t));
-    c->frag_counts = (int32_t *)calloc((size_t)c->n_frag, sizeof(int32_t));
-    c->readlength = r->hdr_readlength;
-    if (!c->R || !c->frag_counts) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
-    if (o->format == 2) {
+    if (!c) { if (err) snprintf(err, errlen, "out of memory"); return EMSAR_HOST_ERR_OOM; }
+    if (mem_bam) bam = mem_bam;
+    else if (o->format == 2) {
         bam = bam_open(path, r);
         if (!bam) FAIL(EMSAR_HOST_ERR_IO, "can't open BAM file %s", path);
     } else {
@@ -414,9 +437,9 @@ static int count_range(const emsar_rsh *r, const char *path, const emsar_aln_opt
     }
 done:
     emsar_lr_close(lr);
-    bam_close(bam);
+    if (!mem_bam) bam_close(bam);
     free(l.a); free(tmp); free(prev); free(line2); free(skip_id); free(end_id);
-    if (rc != EMSAR_HOST_OK) { emsar_counts_free(c); return rc; }
+    if (rc != EMSAR_HOST_OK) { if (!acc) emsar_counts_free(c); return rc; }
     *out = c;
     return EMSAR_HOST_OK;
 }
@@ -428,9 +451,11 @@ typedef struct {
 } range_job;
 static void *range_main(void *a) {
     range_job *j = (range_job *)a;
-    j->rc = count_range(j->r, j->path, j->o, j->begin, j->end, &j->c, &j->got, j->err, sizeof j->err);
+    j->rc = count_range(j->r, j->path, j->o, j->begin, j->end, &j->c, &j->got, j->err, sizeof j->err, NULL, NULL);
     return NULL;
 }
+
+static int host_threads(void);
 
 /* how many ranges: plain seekable text only (not BAM, gzip, stdin), single-end, or default-bowtie paired-end whose
  * mates are named .../1 and .../2 (that is how a range finds the start of a pair); one range per 16 MiB at least */
@@ -452,10 +477,8 @@ static int plan_ranges(const char *path, const emsar_aln_opts *o, int64_t *size_
     }
     emsar_lr_close(lr);
     if (!ok) return 1;
-    long nc = sysconf(_SC_NPROCESSORS_ONLN);
-    int nt = nc > 16 ? 16 : nc < 1 ? 1 : (int)nc;
-    const char *e = getenv("EMSAR_HOST_THREADS");
-    if (e && atoi(e) > 0) nt = atoi(e) > 64 ? 64 : atoi(e);
+    int nt = host_threads();
+    const char *e;
     int64_t min_bytes = (int64_t)16 << 20;
     if ((e = getenv("EMSAR_HOST_RANGE_BYTES")) && atoll(e) > 0) min_bytes = atoll(e);       /* tests use small files */
     int64_t by_size = (int64_t)st.st_size / min_bytes;
@@ -464,15 +487,219 @@ static int plan_ranges(const char *path, const emsar_aln_opts *o, int64_t *size_
     return nt;
 }
 
+static int host_threads(void) {
+    long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    int nt = nc > 16 ? 16 : nc < 1 ? 1 : (int)nc;
+    const char *e = getenv("EMSAR_HOST_THREADS");
+    if (e && atoi(e) > 0) nt = atoi(e) > 64 ? 64 : atoi(e);
+    return nt;
+}
+
+static void counts_add(emsar_counts *c, const emsar_counts *q) {
+    for (int64_t i = 0; i < c->n_rows; i++) c->R[i] += q->R[i];
+    for (int32_t i = 0; i < c->n_frag; i++) c->frag_counts[i] += q->frag_counts[i];
+    c->total_reads += q->total_reads; c->reads_seen += q->reads_seen; c->reads_over_k += q->reads_over_k;
+    c->reads_bad_fraglen += q->reads_bad_fraglen; c->reads_discrepant += q->reads_discrepant; c->reads_no_segment += q->reads_no_segment;
+}
+
+/* ---- single-end BAM counted by a pool of threads ------------------------------------------------------------------------
+ * A BAM record carries its length but no sync mark, so a worker cannot start in the middle of the inflated stream.  The
+ * calling thread therefore walks the stream (inflated ahead of it by pbgzf's own pool), hops from record to record and
+ * cuts it into batches of whole records.  It reads just enough of each record -- refID, FLAG and the read name, all in
+ * the fixed part -- to cut only where a KEPT record opens a new read group (kept = aligned and on the wanted strand:
+ * the same test count_range applies, emsar_functions.c:359,748), so the batches are independent: each worker runs the
+ * sequential loop on its batches and adds into its own counts, and the sums equal the one-thread result exactly.
+ * Paired-end BAM stays on one thread (mates may come in either order, so a cut cannot tell where a pair begins). */
+typedef struct bam_batch { unsigned char *buf; size_t n, cap; int64_t index; struct bam_batch *next; } bam_batch;
+typedef struct {
+    pthread_mutex_t mu; pthread_cond_t cv_work, cv_free;
+    bam_batch *work_head, *work_tail, *free_list;
+    int closing;
+    const emsar_rsh *r; const emsar_aln_opts *o; const bamreader *master;
+    int64_t err_index; int rc; char err[256];                        /* the failing batch that comes first in the file */
+} bam_pool;
+typedef struct { bam_pool *pool; emsar_counts *c; int got; pthread_t th; int started; } bam_worker;
+
+static void *bam_worker_main(void *a) {
+    bam_worker *w = (bam_worker *)a;
+    bam_pool *P = w->pool;
+    for (;;) {
+        pthread_mutex_lock(&P->mu);
+        while (!P->work_head && !P->closing) pthread_cond_wait(&P->cv_work, &P->mu);
+        bam_batch *b = P->work_head;
+        if (b) { P->work_head = b->next; if (!P->work_head) P->work_tail = NULL; }
+        pthread_mutex_unlock(&P->mu);
+        if (!b) return NULL;
+        bamreader view = *P->master;                                  /* header and refID -> tid table shared read-only */
+        view.f = NULL; view.pf = NULL; view.buf = NULL; view.cap = 0;
+        view.mem = b->buf; view.mem_n = b->n; view.mem_pos = 0;
+        emsar_counts *c = NULL; int got = 0; char err[256]; err[0] = 0;
+        int rc = w->c ? count_range(P->r, NULL, P->o, 0, -1, &c, &got, err, sizeof err, &view, w->c) : EMSAR_HOST_ERR_OOM;
+        w->got |= got;
+        pthread_mutex_lock(&P->mu);
+        if (rc != EMSAR_HOST_OK && (P->rc == EMSAR_HOST_OK || b->index < P->err_index)) {
+            P->rc = rc; P->err_index = b->index; snprintf(P->err, sizeof P->err, "%s", err[0] ? err : "out of memory");
+        }
+        b->next = P->free_list; P->free_list = b;
+        pthread_cond_signal(&P->cv_free);
+        pthread_mutex_unlock(&P->mu);
+    }
+}
+
+static bam_batch *bam_batch_get(bam_pool *P) {                        /* blocks until a worker returns one */
+    pthread_mutex_lock(&P->mu);
+    while (!P->free_list) pthread_cond_wait(&P->cv_free, &P->mu);
+    bam_batch *b = P->free_list;
+    P->free_list = b->next;
+    pthread_mutex_unlock(&P->mu);
+    b->n = 0; b->next = NULL;
+    return b;
+}
+static void bam_batch_put(bam_pool *P, bam_batch *b) {
+    pthread_mutex_lock(&P->mu);
+    if (P->work_tail) P->work_tail->next = b; else P->work_head = b;
+    P->work_tail = b;
+    pthread_cond_signal(&P->cv_work);
+    pthread_mutex_unlock(&P->mu);
+}
+
+/* returns -100 when the input is not for this path (the caller then runs the one-thread loop) */
+static int count_bam_parallel(const emsar_rsh *r, const char *path, const emsar_aln_opts *o, emsar_counts **out,
+                              char *err, size_t errlen) {
+    const int nt = host_threads();
+    if (o->format != 2 || o->pe || nt <= 1 || !path || !path[0] || strcmp(path, "-") == 0) return -100;
+    size_t batch_bytes = (size_t)8 << 20;
+    const char *e = getenv("EMSAR_HOST_RANGE_BYTES");                 /* tests: many batches on small files */
+    if (e && atoll(e) > 0) batch_bytes = (size_t)atoll(e);
+    struct stat st;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode) || (!e && st.st_size < (1 << 20))) return -100;
+    bamreader *bam = bam_open(path, r);
+    if (!bam) { if (err) snprintf(err, errlen, "can't open BAM file %s", path); return EMSAR_HOST_ERR_IO; }
+    if (!bam->pf) { bam_close(bam); return -100; }                    /* plain gzip: zlib on one thread */
+    for (int i = 0; i < bam->n_ref; i++) bam->ref_tid[i] = emsar_rsh_tid_of(r, bam->ref[i]);   /* workers only read the table */
+
+    int rc = EMSAR_HOST_OK;
+    const int nq = 2 * nt;
+    bam_pool P;
+    memset(&P, 0, sizeof P);
+    pthread_mutex_init(&P.mu, NULL); pthread_cond_init(&P.cv_work, NULL); pthread_cond_init(&P.cv_free, NULL);
+    P.r = r; P.o = o; P.master = bam; P.rc = EMSAR_HOST_OK;
+    bam_batch *all = (bam_batch *)calloc((size_t)nq, sizeof(*all));
+    bam_worker *w = (bam_worker *)calloc((size_t)nt, sizeof(*w));
+    int n_started = 0;
+    if (!all || !w) rc = EMSAR_HOST_ERR_OOM;
+    for (int i = 0; i < nq && rc == EMSAR_HOST_OK; i++) {
+        all[i].cap = batch_bytes + (1 << 16);
+        all[i].buf = (unsigned char *)malloc(all[i].cap);
+        if (!all[i].buf) rc = EMSAR_HOST_ERR_OOM;
+        all[i].next = P.free_list; P.free_list = &all[i];
+    }
+    for (int t = 0; t < nt && rc == EMSAR_HOST_OK; t++) {
+        w[t].pool = &P;
+        w[t].c = counts_new(r);
+        if (!w[t].c) { rc = EMSAR_HOST_ERR_OOM; break; }
+        if (pthread_create(&w[t].th, NULL, bam_worker_main, &w[t]) == 0) { w[t].started = 1; n_started++; }
+    }
+    if (rc == EMSAR_HOST_OK && n_started == 0) rc = EMSAR_HOST_ERR_OOM;
+
+    int64_t n_batches = 0;
+    int malformed = 0;
+    if (rc == EMSAR_HOST_OK) {
+        bam_batch *cur = bam_batch_get(&P);
+        unsigned char prev[256]; size_t prev_n = 0; int have_prev = 0;
+        for (;;) {
+            unsigned char h[4];
+            long got = bam_get(bam, h, 4);
+            if (got == 0) break;
+            int32_t bs = got == 4 ? le32(h) : -1;
+            if (bs < 32 || bs > (1 << 28)) { malformed = 1; break; }
+            const size_t need = cur->n + 4 + (size_t)bs;
+            if (need > cur->cap) {
+                unsigned char *nb = (unsigned char *)realloc(cur->buf, need + (1 << 16));
+                if (!nb) { rc = EMSAR_HOST_ERR_OOM; break; }
+                cur->buf = nb; cur->cap = need + (1 << 16);
+            }
+            unsigned char *rec = cur->buf + cur->n;
+            memcpy(rec, h, 4);
+            if (bam_rd(bam, rec + 4, (size_t)bs)) { malformed = 1; break; }
+            const unsigned char *q = rec + 4;
+            const int32_t refid = le32(q);
+            const int l_name = q[8], flag = q[14] | (q[15] << 8);
+            const char strand = (flag & 0x10) ? '-' : '+';
+            const int kept = refid >= 0 && refid < bam->n_ref && 32 + (size_t)l_name <= (size_t)bs && l_name >= 1 &&
+                             !(o->strand != 0 && o->strand != strand);
+            if (kept) {
+                const size_t nl = strnlen((const char *)(q + 32), (size_t)l_name);
+                const int new_group = !have_prev || nl != prev_n || memcmp(prev, q + 32, nl) != 0;
+                if (new_group && cur->n >= batch_bytes) {             /* this record opens the next batch */
+                    bam_batch *nb = bam_batch_get(&P);
+                    if (4 + (size_t)bs > nb->cap) {
+                        unsigned char *g = (unsigned char *)realloc(nb->buf, 4 + (size_t)bs + (1 << 16));
+                        if (!g) { bam_batch_put(&P, nb); rc = EMSAR_HOST_ERR_OOM; break; }
+                        nb->buf = g; nb->cap = 4 + (size_t)bs + (1 << 16);
+                    }
+                    memcpy(nb->buf, rec, 4 + (size_t)bs);
+                    nb->n = 0;
+                    cur->index = n_batches++;
+                    bam_batch_put(&P, cur);
+                    cur = nb; rec = cur->buf; q = rec + 4;
+                    pthread_mutex_lock(&P.mu);
+                    const int failed = P.rc != EMSAR_HOST_OK;
+                    pthread_mutex_unlock(&P.mu);
+                    if (failed) { cur->n = 0; break; }                /* a batch already failed: whatever follows cannot come first */
+                }
+                memcpy(prev, q + 32, nl); prev_n = nl; have_prev = 1;
+            }
+            cur->n += 4 + (size_t)bs;
+        }
+        cur->index = n_batches++;
+        bam_batch_put(&P, cur);                                       /* the last batch (possibly empty) */
+    }
+    pthread_mutex_lock(&P.mu);
+    P.closing = 1;
+    pthread_cond_broadcast(&P.cv_work);
+    pthread_mutex_unlock(&P.mu);
+    for (int t = 0; t < nt; t++) if (w && w[t].started) pthread_join(w[t].th, NULL);
+
+    emsar_counts *c = NULL;
+    int got = 0;
+    if (rc == EMSAR_HOST_OK && P.rc != EMSAR_HOST_OK) { rc = P.rc; if (err) snprintf(err, errlen, "%s", P.err); }
+    if (rc == EMSAR_HOST_OK && malformed) { rc = EMSAR_HOST_ERR_FORMAT; if (err) snprintf(err, errlen, "malformed BAM record"); }
+    if (rc == EMSAR_HOST_ERR_OOM && err) snprintf(err, errlen, "out of memory");
+    if (rc == EMSAR_HOST_OK) {
+        for (int t = 0; t < nt; t++) {
+            got |= w[t].got;
+            if (!c) { c = w[t].c; w[t].c = NULL; } else counts_add(c, w[t].c);
+        }
+        if (!got) {
+            rc = EMSAR_HOST_ERR_FORMAT;
+            if (err) snprintf(err, errlen, "no usable alignment in %s (the reference stops with 'NULL alignment list')", path);
+        }
+    }
+    if (getenv("EMSAR_HOST_DEBUG")) fprintf(stderr, "emsar_count_alignments: BAM, %lld batch(es) on %d thread(s)\n", (long long)n_batches, n_started);
+    for (int t = 0; w && t < nt; t++) emsar_counts_free(w[t].c);
+    for (int i = 0; all && i < nq; i++) free(all[i].buf);
+    free(all); free(w);
+    pthread_mutex_destroy(&P.mu); pthread_cond_destroy(&P.cv_work); pthread_cond_destroy(&P.cv_free);
+    bam_close(bam);
+    if (rc != EMSAR_HOST_OK) { emsar_counts_free(c); return rc; }
+    *out = c;
+    return EMSAR_HOST_OK;
+}
+
 int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln_opts *o, emsar_counts **out,
                            char *err, size_t errlen) {
     *out = NULL;
+    {
+        int prc = count_bam_parallel(r, path, o, out, err, errlen);
+        if (prc != -100) return prc;
+    }
     int64_t size = 0;
     const int nt = plan_ranges(path, o, &size);
     int rc = EMSAR_HOST_OK, got = 0;
     if (getenv("EMSAR_HOST_DEBUG")) fprintf(stderr, "emsar_count_alignments: %d range(s) over %lld bytes\n", nt, (long long)size);
     if (nt <= 1) {
-        rc = count_range(r, path, o, 0, -1, out, &got, err, errlen);
+        rc = count_range(r, path, o, 0, -1, out, &got, err, errlen, NULL, NULL);
         if (rc == EMSAR_HOST_OK && !got) {
             emsar_counts_free(*out); *out = NULL;
             if (err) snprintf(err, errlen, "no usable alignment in %s (the reference stops with 'NULL alignment list')", path);
@@ -505,10 +732,7 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
         c = job[0].c; job[0].c = NULL;
         for (int t = 1; t < nt && rc == EMSAR_HOST_OK; t++) {
             const emsar_counts *q = job[t].c;
-            for (int64_t i = 0; i < c->n_rows; i++) c->R[i] += q->R[i];
-            for (int32_t i = 0; i < c->n_frag; i++) c->frag_counts[i] += q->frag_counts[i];
-            c->total_reads += q->total_reads; c->reads_seen += q->reads_seen; c->reads_over_k += q->reads_over_k;
-            c->reads_bad_fraglen += q->reads_bad_fraglen; c->reads_discrepant += q->reads_discrepant; c->reads_no_segment += q->reads_no_segment;
+            counts_add(c, q);
             if (q->readlength != r->hdr_readlength) {                /* learnt from the data (paired-end, header says -1) */
                 if (c->readlength == r->hdr_readlength) c->readlength = q->readlength;
                 else if (c->readlength != q->readlength) {

@@ -44,6 +44,75 @@ def test_bam_counts_equal_text_counts(bam_case, threads, monkeypatch):
     assert got.total_reads == want.total_reads and got.stats == want.stats
 
 
+@pytest.mark.parametrize("threads,batch", [("2", "1"), ("4", "3000"), ("16", "40000"), ("3", "100000000")])
+def test_bam_records_counted_in_parallel_batches(bam_case, threads, batch, monkeypatch, capfd):
+    """Single-end BAM: the calling thread cuts the inflated stream into batches of whole records at read-group
+    boundaries, a pool counts them (align.c, count_bam_parallel).  Any batch size -- one group per batch included --
+    gives the counts of the one-thread loop, with either strand filter."""
+    r, bam, want, d = bam_case
+    monkeypatch.setenv("EMSAR_HOST_THREADS", threads)
+    monkeypatch.setenv("EMSAR_HOST_RANGE_BYTES", batch)
+    monkeypatch.setenv("EMSAR_HOST_DEBUG", "1")
+    got = r.count(bam, fmt=2)
+    dbg = capfd.readouterr().err
+    assert "BAM, " in dbg and "on %s thread(s)" % threads in dbg
+    n_batches = int(dbg.split("BAM, ")[1].split(" batch")[0])
+    assert n_batches > 50 if batch == "1" else n_batches >= 1
+    np.testing.assert_array_equal(got.R, want.R)
+    np.testing.assert_array_equal(got.frag_counts, want.frag_counts)
+    assert got.total_reads == want.total_reads and got.stats == want.stats
+    def outcome(n_threads, strand):
+        monkeypatch.setenv("EMSAR_HOST_THREADS", n_threads)
+        try:
+            c = r.count(bam, fmt=2, strand=strand)
+        except HL.HostError as e:                                  # a strand nobody maps to: 'NULL alignment list' either way
+            return str(e)
+        return (c.R.tobytes(), c.frag_counts.tobytes(), c.total_reads, c.stats)
+
+    for strand in ("ssf", "ssr"):
+        assert outcome("1", strand) == outcome(threads, strand)
+
+
+@pytest.mark.parametrize("case", ["toy5_bam", "toy5_pe_bam"])
+def test_golden_bam_fixtures_in_parallel_batches(case, monkeypatch, capfd):
+    """The reference's own BAM inputs (both strands, unaligned records between the kept ones): one group per batch gives
+    the one-thread counts; the paired-end file is left to the one-thread loop."""
+    _build.build_host()
+    fx = get_fixture(case)
+    r = HL.HostRsh(os.path.join(fx.dir, "index.rsh"))
+    pe = 1 if "pe" in case else 0
+    path = os.path.join(fx.dir, "reads.bam")
+    monkeypatch.setenv("EMSAR_HOST_DEBUG", "1")
+    for strand in ("ns", "ssf", "ssr") if not pe else ("ns", "ssfr", "ssrf"):
+        res = []
+        for threads, batch in (("1", "1"), ("4", "1"), ("3", "200")):
+            monkeypatch.setenv("EMSAR_HOST_THREADS", threads)
+            monkeypatch.setenv("EMSAR_HOST_RANGE_BYTES", batch)
+            capfd.readouterr()
+            try:
+                c = r.count(path, pe=pe, strand=strand, fmt=2)
+                res.append((c.R.tobytes(), c.frag_counts.tobytes(), c.total_reads, c.stats))
+            except HL.HostError as e:
+                res.append(str(e))
+            assert ("BAM, " in capfd.readouterr().err) == (threads != "1" and not pe)
+        assert res[0] == res[1] == res[2]
+
+
+def test_parallel_bam_errors_match_the_one_thread_loop(bam_case, monkeypatch):
+    r, bam, _, d = bam_case
+    raw = open(bam, "rb").read()
+    p = str(d / "trunc2.bam")
+    open(p, "wb").write(raw[: len(raw) // 2])
+    msgs = []
+    for threads in ("1", "4"):
+        monkeypatch.setenv("EMSAR_HOST_THREADS", threads)
+        monkeypatch.setenv("EMSAR_HOST_RANGE_BYTES", "5000")
+        with pytest.raises(HL.HostError) as e:
+            r.count(p, fmt=2)
+        msgs.append(str(e.value))
+    assert msgs[0] == msgs[1]
+
+
 def test_damaged_blocks_are_errors(bam_case):
     r, bam, _, d = bam_case
     raw = bytearray(open(bam, "rb").read())

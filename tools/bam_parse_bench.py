@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BAM ingestion with the parallel BGZF reader: the same synthetic reads as default-bowtie text and as BAM, counted by
-emsar_count_alignments with 1 and N inflate threads.  CPU only.
+emsar_count_alignments with 1 and N host threads (BGZF inflate pool + record-counting pool).  CPU only.
 
     python tools/bam_parse_bench.py [n_tx] [n_reads] [largest_family]
 """
@@ -38,8 +38,8 @@ with tempfile.TemporaryDirectory() as d:
     print("reads %d, alignments text %.1f MB, BAM %.1f MB" % (n_reads, os.path.getsize(txt) / 1e6, os.path.getsize(bam) / 1e6))
     t0 = time.perf_counter(); a = rsh.count(txt); t_txt = time.perf_counter() - t0
     res = {}
-    for th in ("1", str(min(16, os.cpu_count() or 1))):
+    for th in ("1", "4", str(min(16, os.cpu_count() or 1))):
         os.environ["EMSAR_HOST_THREADS"] = th
         t0 = time.perf_counter(); b = rsh.count(bam, fmt=2); res[th] = time.perf_counter() - t0
         assert np.array_equal(a.R, b.R) and a.total_reads == b.total_reads
-    print("count_alignments: bowtie text %.2f s; BAM " % t_txt + ", ".join("%s inflate thread(s) %.2f s" % kv for kv in res.items()))
+    print("count_alignments: bowtie text %.2f s; BAM " % t_txt + ", ".join("%s thread(s) %.2f s" % kv for kv in res.items()))
