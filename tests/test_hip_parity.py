@@ -239,6 +239,29 @@ def test_full_size_properties_cfg2(dev):
         assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
 
 
+@pytest.mark.parametrize("multi", ["0", "2"])
+def test_loglik_of_unweighted_rows_at_extreme_theta(monkeypatch, multi):
+    """The unweighted TILED kernels take the log of a product of six row sums instead of six logs; a product that
+    leaves the double range falls back to the per-row logs.  theta of 1e-70 / 1e+70 everywhere (products 1e-420 / 1e+420),
+    and a mixture in which single transcripts sit at 1e-300, must give the oracle's likelihood."""
+    s = synth.make_config("cfg3", 0.002)
+    m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
+    rng = np.random.default_rng(8)
+    base = rng.uniform(0.5, 2.0, size=s["n_tx"])
+    mixed = base.copy()
+    mixed[rng.random(s["n_tx"]) < 0.3] = 1e-300
+    monkeypatch.setenv("EMSAR_HIP_TILED_MULTI", multi)
+    with EmsarHip(0) as ctx:
+        ctx.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
+        ctx.upload_sample(None, None, s["den"])
+        for th in (base, base * 1e-70, base * 1e70, mixed):
+            th = np.where(s["den"] > 0, th, 0.0)
+            _, ll = m.em_step(th, s["den"], n_threads=4)
+            ctx.set_theta(th)
+            _, ll_dev = ctx.run_passes(1, want_loglik=True)
+            assert np.isfinite(ll_dev) and abs(ll_dev - ll) <= 1e-11 * abs(ll) + 1e-9, (th[:3], ll_dev, ll)
+
+
 def test_tiled_pair_and_single_kernels_match_oracle(monkeypatch):
     """Unweighted TILED passes run two tiles per workgroup (k_pass_tiled_multi) only when the tiles outnumber the chip's
     workgroup slots, one (k_pass_tiled) below that; the knob forces either kernel on a matrix of a few dozen tiles.  The
