@@ -13,12 +13,14 @@
  */
 #include "emsar_host.h"
 
+#include <pthread.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <zlib.h>
 
 /* ---------- line reader over zlib (reads plain text and .gz alike) ----------
@@ -170,32 +172,180 @@ static int cmp_mrow(const void *a, const void *b) {
     return x->seq < y->seq ? -1 : (x->seq > y->seq);
 }
 
-/* split "a,b,c," into ints; returns count (atoi semantics like the reference) */
+/* split "a,b,c," into ints; returns count.  atoi semantics like the reference (leading blanks, a sign, digits, the rest
+ * of the field ignored), without the libc call per number: the EUMA lists are most of a paired-end rsh */
 static int parse_int_list(const char *s, int32_t *out, int max) {
     int n = 0;
     while (*s && n < max) {
-        const char *e = strchr(s, ',');
-        out[n++] = atoi(s);
-        if (!e) break;
-        s = e + 1;
+        const char *p = s;
+        while (*p == ' ' || (*p >= '\t' && *p <= '\r')) p++;
+        int neg = 0;
+        if (*p == '-') { neg = 1; p++; } else if (*p == '+') p++;
+        uint32_t v = 0;
+        while (*p >= '0' && *p <= '9') v = v * 10u + (uint32_t)(*p++ - '0');
+        out[n++] = neg ? (int32_t)(0u - v) : (int32_t)v;
+        while (*p && *p != ',') p++;
+        if (!*p) break;
+        s = p + 1;
     }
     return n;
 }
 
 #define FAIL(code, ...) do { if (err) snprintf(err, errlen, __VA_ARGS__); rc = (code); goto done; } while (0)
 
+/* What one worker collects from its part of the file (the whole body when the file is read on one thread): the
+ * multi-tid nodes, the single-tid nodes and the index lines, each in file order.  emsar_rsh_read applies them part by
+ * part, so "the last line for a tid wins" (1488) and the list order of equal (size, first tid) nodes stay those of a
+ * sequential read. */
+typedef struct { int32_t tid; int32_t *eu; } srow;
+typedef struct { int32_t tid; char *name; } nrow;
+typedef struct int_chunk { struct int_chunk *next; size_t used, cap; int32_t v[]; } int_chunk;
+typedef struct {
+    int_chunk *ints;                                  /* tids and EUMA vectors of the part: a few big chunks, not two mallocs per line */
+    const char *path; int64_t begin, end;            /* lines STARTING in [begin, end); end < 0: to the end of the file */
+    linereader *lr;                                   /* given: continue on this reader instead of opening the file */
+    int32_t n_tx, nfl;
+    mrow *multi; size_t n_multi, cap_multi;
+    srow *single; size_t n_single, cap_single;
+    nrow *names; size_t n_names, cap_names;
+    int32_t max_t_size;
+    int rc; char err[256];
+} rsh_part;
+
+static int32_t *part_ints(rsh_part *j, size_t n, int zero) {
+    if (!j->ints || j->ints->cap - j->ints->used < n) {
+        size_t cap = n > ((size_t)1 << 20) ? n : ((size_t)1 << 20);
+        int_chunk *c = (int_chunk *)malloc(sizeof(int_chunk) + cap * sizeof(int32_t));
+        if (!c) return NULL;
+        c->next = j->ints; c->used = 0; c->cap = cap; j->ints = c;
+    }
+    int32_t *p = j->ints->v + j->ints->used;
+    j->ints->used += n;
+    if (zero) memset(p, 0, n * sizeof(int32_t));
+    return p;
+}
+
+static void *rsh_part_main(void *a) {
+    rsh_part *j = (rsh_part *)a;
+    char *err = j->err; const size_t errlen = sizeof j->err;
+    int rc = EMSAR_HOST_OK;
+    linereader *lr = j->lr ? j->lr : (linereader *)emsar_lr_open_at(j->path, j->begin);
+    if (!lr) FAIL(EMSAR_HOST_ERR_IO, "can't open input rsh file %s", j->path);
+    char *line;
+    while ((line = lr_next(lr))) {
+        if (j->end >= 0 && lr->last >= j->end) break;
+        if (line[0] == '#') {
+            FAIL(EMSAR_HOST_ERR_FORMAT, "more than one rsh header line");
+        } else if (line[0] == '@') {                                       /* parse_rsh_indexline, 1381-1403 */
+            char *tab = strchr(line, '\t');
+            int tid = atoi(line + 1);
+            if (!tab || tid < 0 || tid >= j->n_tx) FAIL(EMSAR_HOST_ERR_FORMAT, "bad rsh index line: %.60s", line);
+            char *e = strchr(tab + 1, '\t'); if (e) *e = 0;
+            if (j->n_names == j->cap_names) {
+                j->cap_names = j->cap_names ? j->cap_names * 2 : 4096;
+                nrow *nn = (nrow *)realloc(j->names, j->cap_names * sizeof(nrow));
+                if (!nn) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+                j->names = nn;
+            }
+            char *nm = strdup(tab + 1);
+            if (!nm) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+            j->names[j->n_names].tid = tid; j->names[j->n_names++].name = nm;
+        } else if (line[0] == 'c' || line[0] == 0) {
+            continue;                                                      /* column headings (1370) */
+        } else {                                                           /* parse_rsh_mainline, 1432-1510 */
+            char *f[5] = {line, NULL, NULL, NULL, NULL};
+            int nf = 1;
+            for (char *p = line; *p && nf < 5; p++) if (*p == '\t') { *p = 0; f[nf++] = p + 1; }
+            if (nf < 3) FAIL(EMSAR_HOST_ERR_FORMAT, "short rsh segment line");
+            int size = atoi(f[1]), tid0 = atoi(f[2]);
+            const char *others = nf > 3 ? f[3] : "", *eumas = nf > 4 ? f[4] : "";
+            if (f[4]) { char *e = strchr(f[4], '\t'); if (e) *e = 0; }
+            if (size < 1 || tid0 < 0 || tid0 >= j->n_tx) FAIL(EMSAR_HOST_ERR_FORMAT, "bad segment line (size %d tid %d)", size, tid0);
+            if (eumas[0] == 0) continue;                                   /* no EUMA -> no node (1486) */
+            int32_t *eu = part_ints(j, (size_t)j->nfl, 1);
+            if (!eu) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+            parse_int_list(eumas, eu, j->nfl);
+            if (size == 1) {                                               /* rshbucket_single[tid0]=q: last wins (1488) */
+                if (j->n_single == j->cap_single) {
+                    j->cap_single = j->cap_single ? j->cap_single * 2 : 4096;
+                    srow *ns = (srow *)realloc(j->single, j->cap_single * sizeof(srow));
+                    if (!ns) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+                    j->single = ns;
+                }
+                j->single[j->n_single].tid = tid0; j->single[j->n_single++].eu = eu;
+                continue;
+            }
+            if (j->n_multi == j->cap_multi) {
+                j->cap_multi = j->cap_multi ? j->cap_multi * 2 : 1024;
+                mrow *nm = (mrow *)realloc(j->multi, j->cap_multi * sizeof(mrow));
+                if (!nm) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+                j->multi = nm;
+            }
+            mrow *m = &j->multi[j->n_multi];
+            m->size = size; m->tid0 = tid0; m->seq = (int64_t)j->n_multi; m->euma = eu;
+            m->tids = part_ints(j, (size_t)size, 0);
+            if (!m->tids) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+            j->n_multi++;
+            m->tids[0] = tid0;
+            int got = parse_int_list(others, m->tids + 1, size - 1);
+            if (got != size - 1) FAIL(EMSAR_HOST_ERR_FORMAT, "segment line lists %d other tids, %d expected", got, size - 1);
+            for (int i = 1; i < size; i++) if (m->tids[i] < 0 || m->tids[i] >= j->n_tx) FAIL(EMSAR_HOST_ERR_FORMAT, "tid out of range in segment line");
+            if (size > j->max_t_size) j->max_t_size = size;
+        }
+    }
+done:
+    if (lr && !j->lr) emsar_lr_close(lr);
+    j->rc = rc;
+    return NULL;
+}
+
+static void rsh_part_free(rsh_part *j) {
+    for (int_chunk *c = j->ints; c;) { int_chunk *n = c->next; free(c); c = n; }
+    for (size_t i = 0; i < j->n_names; i++) free(j->names[i].name);
+    free(j->multi); free(j->single); free(j->names);
+}
+
+/* rows [lo, hi) of the finished table copied from the parts' chunks, several row ranges side by side */
+typedef struct { emsar_rsh *r; const mrow *multi; int32_t *const *single; int64_t lo, hi; } pack_job;
+static void *pack_main(void *a) {
+    pack_job *p = (pack_job *)a;
+    emsar_rsh *r = p->r;
+    const size_t nfl = (size_t)r->nfl;
+    for (int64_t c = p->lo; c < p->hi; c++) {
+        int32_t *dst = r->euma + (size_t)c * nfl;
+        if (c < r->n_tx) {
+            r->col_idx[r->row_ptr[c]] = (int32_t)c;
+            if (p->single[c]) { memcpy(dst, p->single[c], sizeof(int32_t) * nfl); r->has_node[c] = 1; }
+            else { memset(dst, 0, sizeof(int32_t) * nfl); r->has_node[c] = 0; }
+        } else {
+            const mrow *m = &p->multi[c - r->n_tx];
+            memcpy(r->col_idx + r->row_ptr[c], m->tids, sizeof(int32_t) * (size_t)m->size);
+            memcpy(dst, m->euma, sizeof(int32_t) * nfl);
+            r->has_node[c] = 1;
+        }
+    }
+    return NULL;
+}
+
+/* The body of a plain (uncompressed, seekable) rsh is parsed in byte ranges by up to 16 threads (EMSAR_HOST_THREADS), one
+ * range per 16 MiB at least (EMSAR_HOST_RANGE_BYTES); .gz and stdin on the calling thread. */
 int emsar_rsh_read(const char *path, emsar_rsh **out, char *err, size_t errlen) {
     int rc = EMSAR_HOST_OK;
     linereader lr = {0};
     emsar_rsh *r = (emsar_rsh *)calloc(1, sizeof(*r));
-    mrow *multi = NULL; size_t n_multi = 0, cap_multi = 0;
+    rsh_part *part = NULL; int n_part = 0;
+    pthread_t *th = NULL;
+    mrow *multi = NULL; size_t n_multi = 0;
     int32_t **single = NULL;   /* EUMA vector of the single-tid node of each tid, NULL if none */
     int have_hdr = 0;
+    const int dbg = getenv("EMSAR_HOST_DEBUG") != NULL;
+    struct timespec ts0, ts1, ts2, ts3;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
     *out = NULL;
     if (!r) return EMSAR_HOST_ERR_OOM;
     if (lr_open(&lr, path)) FAIL(EMSAR_HOST_ERR_IO, "can't open input rsh file %s", path);
     char *line;
-    while ((line = lr_next(&lr))) {
+    while (!have_hdr && (line = lr_next(&lr))) {
         if (line[0] == '#') {                                              /* parse_rsh_headerline, 1406-1430 */
             int a[5] = {0, 0, 0, 0, -1};
             if (sscanf(line + 1, "%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4]) < 4) FAIL(EMSAR_HOST_ERR_FORMAT, "bad rsh header line");
@@ -210,51 +360,64 @@ int emsar_rsh_read(const char *path, emsar_rsh **out, char *err, size_t errlen) 
             single = (int32_t **)calloc((size_t)r->n_tx, sizeof(int32_t *));
             if (!r->names || !single) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
             have_hdr = 1;
-        } else if (line[0] == '@') {                                       /* parse_rsh_indexline, 1381-1403 */
-            if (!have_hdr) FAIL(EMSAR_HOST_ERR_FORMAT, "rsh index line before the header");
-            char *tab = strchr(line, '\t');
-            int tid = atoi(line + 1);
-            if (!tab || tid < 0 || tid >= r->n_tx) FAIL(EMSAR_HOST_ERR_FORMAT, "bad rsh index line: %.60s", line);
-            char *e = strchr(tab + 1, '\t'); if (e) *e = 0;
-            free(r->names[tid]);
-            r->names[tid] = strdup(tab + 1);
-        } else if (line[0] == 'c' || line[0] == 0) {
-            continue;                                                      /* column headings (1370) */
-        } else {                                                           /* parse_rsh_mainline, 1432-1510 */
-            if (!have_hdr) FAIL(EMSAR_HOST_ERR_FORMAT, "rsh segment line before the header");
-            char *f[5] = {line, NULL, NULL, NULL, NULL};
-            int nf = 1;
-            for (char *p = line; *p && nf < 5; p++) if (*p == '\t') { *p = 0; f[nf++] = p + 1; }
-            if (nf < 3) FAIL(EMSAR_HOST_ERR_FORMAT, "short rsh segment line");
-            int size = atoi(f[1]), tid0 = atoi(f[2]);
-            const char *others = nf > 3 ? f[3] : "", *eumas = nf > 4 ? f[4] : "";
-            if (f[4]) { char *e = strchr(f[4], '\t'); if (e) *e = 0; }
-            if (size < 1 || tid0 < 0 || tid0 >= r->n_tx) FAIL(EMSAR_HOST_ERR_FORMAT, "bad segment line (size %d tid %d)", size, tid0);
-            if (eumas[0] == 0) continue;                                   /* no EUMA -> no node (1486) */
-            int32_t *eu = (int32_t *)calloc((size_t)r->nfl, sizeof(int32_t));
-            if (!eu) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
-            parse_int_list(eumas, eu, r->nfl);
-            if (size == 1) { free(single[tid0]); single[tid0] = eu; continue; }   /* rshbucket_single[tid0]=q: last wins (1488) */
-            if (n_multi == cap_multi) {
-                cap_multi = cap_multi ? cap_multi * 2 : 1024;
-                mrow *nm = (mrow *)realloc(multi, cap_multi * sizeof(mrow));
-                if (!nm) { free(eu); FAIL(EMSAR_HOST_ERR_OOM, "out of memory"); }
-                multi = nm;
-            }
-            mrow *m = &multi[n_multi];
-            m->size = size; m->tid0 = tid0; m->seq = (int64_t)n_multi; m->euma = eu;
-            m->tids = (int32_t *)malloc(sizeof(int32_t) * (size_t)size);
-            if (!m->tids) { free(eu); FAIL(EMSAR_HOST_ERR_OOM, "out of memory"); }
-            n_multi++;
-            m->tids[0] = tid0;
-            int got = parse_int_list(others, m->tids + 1, size - 1);
-            if (got != size - 1) FAIL(EMSAR_HOST_ERR_FORMAT, "segment line lists %d other tids, %d expected", got, size - 1);
-            for (int i = 1; i < size; i++) if (m->tids[i] < 0 || m->tids[i] >= r->n_tx) FAIL(EMSAR_HOST_ERR_FORMAT, "tid out of range in segment line");
-            if (size > r->max_t_size) r->max_t_size = size;
-        }
+        } else if (line[0] == '@') FAIL(EMSAR_HOST_ERR_FORMAT, "rsh index line before the header");
+        else if (line[0] == 'c' || line[0] == 0) continue;
+        else FAIL(EMSAR_HOST_ERR_FORMAT, "rsh segment line before the header");
     }
     if (!have_hdr) FAIL(EMSAR_HOST_ERR_FORMAT, "rsh file has no header line");
+
+    /* ---- the body: one part on this reader, or byte ranges side by side ---- */
+    {
+        const int64_t body = lr.base + (int64_t)lr.pos;                    /* offset of the line after the header */
+        int nt = 1;
+        struct stat st;
+        if (path && path[0] && strcmp(path, "-") != 0 && gzdirect(lr.f) && stat(path, &st) == 0 && S_ISREG(st.st_mode)) {
+            long nc = sysconf(_SC_NPROCESSORS_ONLN);
+            nt = nc > 16 ? 16 : nc < 1 ? 1 : (int)nc;
+            const char *e = getenv("EMSAR_HOST_THREADS");
+            if (e && atoi(e) > 0) nt = atoi(e) > 64 ? 64 : atoi(e);
+            int64_t min_bytes = (int64_t)16 << 20;
+            if ((e = getenv("EMSAR_HOST_RANGE_BYTES")) && atoll(e) > 0) min_bytes = atoll(e);
+            const int64_t by_size = ((int64_t)st.st_size - body) / min_bytes;
+            if (by_size < nt) nt = by_size < 1 ? 1 : (int)by_size;
+        }
+        if (dbg) fprintf(stderr, "emsar_rsh_read: %d part(s)\n", nt);
+        part = (rsh_part *)calloc((size_t)nt, sizeof(*part));
+        th = (pthread_t *)calloc((size_t)nt, sizeof(*th));
+        if (!part || !th) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+        n_part = nt;
+        for (int t = 0; t < nt; t++) { part[t].path = path; part[t].n_tx = r->n_tx; part[t].nfl = r->nfl; part[t].max_t_size = r->max_t_size; }
+        if (nt == 1) { part[0].lr = &lr; part[0].begin = body; part[0].end = -1; rsh_part_main(&part[0]); }
+        else {
+            const int64_t span = ((int64_t)st.st_size - body) / nt;
+            for (int t = 0; t < nt; t++) { part[t].begin = body + span * t; part[t].end = t + 1 < nt ? body + span * (t + 1) : -1; }
+            int started = 0;
+            for (int t = 1; t < nt; t++) { if (pthread_create(&th[t], NULL, rsh_part_main, &part[t]) != 0) break; started = t; }
+            for (int t = started + 1; t < nt; t++) rsh_part_main(&part[t]);  /* could not spawn: run it here */
+            rsh_part_main(&part[0]);
+            for (int t = 1; t <= started; t++) pthread_join(th[t], NULL);
+        }
+        for (int t = 0; t < nt; t++)                                       /* the first failing part (in file order) names the error */
+            if (part[t].rc != EMSAR_HOST_OK) { if (err) snprintf(err, errlen, "%s", part[t].err); rc = part[t].rc; goto done; }
+    }
+    /* ---- apply the parts in file order ---- */
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    for (int t = 0; t < n_part; t++) {
+        rsh_part *j = &part[t];
+        for (size_t i = 0; i < j->n_names; i++) { free(r->names[j->names[i].tid]); r->names[j->names[i].tid] = j->names[i].name; j->names[i].name = NULL; }
+        for (size_t i = 0; i < j->n_single; i++) single[j->single[i].tid] = j->single[i].eu;      /* the vectors stay in the part's chunks */
+        if (j->max_t_size > r->max_t_size) r->max_t_size = j->max_t_size;
+        n_multi += j->n_multi;
+    }
     for (int32_t t = 0; t < r->n_tx; t++) if (!r->names[t]) FAIL(EMSAR_HOST_ERR_FORMAT, "no @ line for tid %d", t);
+    multi = (mrow *)malloc(sizeof(mrow) * (n_multi ? n_multi : 1));
+    if (!multi) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+    {
+        size_t k = 0;
+        for (int t = 0; t < n_part; t++) {
+            for (size_t i = 0; i < part[t].n_multi; i++) { multi[k] = part[t].multi[i]; multi[k].seq = (int64_t)k; k++; }
+        }
+    }
     /* scan order of the multi-tid nodes: size, first tid, list (= file) order */
     qsort(multi, n_multi, sizeof(mrow), cmp_mrow);
     r->n_rows = (int64_t)r->n_tx + (int64_t)n_multi;
@@ -262,31 +425,39 @@ int emsar_rsh_read(const char *path, emsar_rsh **out, char *err, size_t errlen) 
     for (size_t i = 0; i < n_multi; i++) nnz += (uint64_t)multi[i].size;
     r->row_ptr = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)r->n_rows + 1));
     r->col_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)nnz);
-    r->euma = (int32_t *)calloc((size_t)r->n_rows * (size_t)r->nfl, sizeof(int32_t));
-    r->has_node = (uint8_t *)calloc((size_t)r->n_rows, 1);
+    r->euma = (int32_t *)malloc(sizeof(int32_t) * (size_t)r->n_rows * (size_t)r->nfl + 1);
+    r->has_node = (uint8_t *)malloc((size_t)r->n_rows + 1);
     if (!r->row_ptr || !r->col_idx || !r->euma || !r->has_node) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
-    uint64_t k = 0;
-    for (int32_t t = 0; t < r->n_tx; t++) {
-        r->row_ptr[t] = k; r->col_idx[k++] = t;
-        if (single[t]) { memcpy(r->euma + (size_t)t * (size_t)r->nfl, single[t], sizeof(int32_t) * (size_t)r->nfl); r->has_node[t] = 1; }
+    {
+        uint64_t k = 0;
+        for (int32_t t = 0; t < r->n_tx; t++) r->row_ptr[t] = k++;
+        for (size_t i = 0; i < n_multi; i++) { r->row_ptr[(size_t)r->n_tx + i] = k; k += (uint64_t)multi[i].size; }
+        r->row_ptr[r->n_rows] = k;
+        int np = n_part;                                                   /* as many packers as there were parsers */
+        if (np > 64) np = 64;
+        pack_job pj[64];
+        pthread_t pt[64];
+        int started = 0;
+        for (int t = 0; t < np; t++) pj[t] = (pack_job){r, multi, single, r->n_rows * t / np, r->n_rows * (t + 1) / np};
+        for (int t = 1; t < np; t++) { if (pthread_create(&pt[t], NULL, pack_main, &pj[t]) != 0) break; started = t; }
+        for (int t = started + 1; t < np; t++) pack_main(&pj[t]);
+        pack_main(&pj[0]);
+        for (int t = 1; t <= started; t++) pthread_join(pt[t], NULL);
     }
-    for (size_t i = 0; i < n_multi; i++) {
-        int64_t c = (int64_t)r->n_tx + (int64_t)i;
-        r->row_ptr[c] = k;
-        memcpy(r->col_idx + k, multi[i].tids, sizeof(int32_t) * (size_t)multi[i].size);
-        k += (uint64_t)multi[i].size;
-        memcpy(r->euma + (size_t)c * (size_t)r->nfl, multi[i].euma, sizeof(int32_t) * (size_t)r->nfl);
-        r->has_node[c] = 1;
-    }
-    r->row_ptr[r->n_rows] = k;
+    clock_gettime(CLOCK_MONOTONIC, &ts2);
     r->name_index = ni_build(r->names, r->n_tx);
     r->set_index = si_build(r);
     if (!r->name_index || !r->set_index) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
+    clock_gettime(CLOCK_MONOTONIC, &ts3);
+#define SECS(a, b) ((double)((b).tv_sec - (a).tv_sec) + 1e-9 * (double)((b).tv_nsec - (a).tv_nsec))
+    if (dbg) fprintf(stderr, "emsar_rsh_read: parse %.3f s, order + pack %.3f s, indexes %.3f s\n", SECS(ts0, ts1), SECS(ts1, ts2), SECS(ts2, ts3));
+#undef SECS
 done:
     lr_close(&lr);
-    if (single) { for (int32_t t = 0; t < r->n_tx; t++) free(single[t]); free(single); }
-    for (size_t i = 0; i < n_multi; i++) { free(multi[i].tids); free(multi[i].euma); }
+    free(single);
     free(multi);
+    for (int t = 0; t < n_part; t++) rsh_part_free(&part[t]);
+    free(part); free(th);
     if (rc != EMSAR_HOST_OK) { emsar_rsh_free(r); return rc; }
     *out = r;
     return EMSAR_HOST_OK;

@@ -103,3 +103,75 @@ def test_ranges_are_really_used(tmp_path, monkeypatch, capfd):
     assert "6 range(s)" in capfd.readouterr().err
     _count(r, aln_path(fx.dir)[0], monkeypatch, 6, 1000)               # gzip input: sequential
     assert "1 range(s)" in capfd.readouterr().err
+
+
+def _rsh_arrays(r):
+    return (r.names, r.row_ptr.tobytes(), r.col_idx.tobytes(), r.euma.tobytes(), r.has_node.tobytes())
+
+
+@pytest.mark.parametrize("case", ["toy5_se50", "toy5_pe", "syn300_se", "syn2k_se"])
+def test_rsh_body_parsed_in_ranges(case, tmp_path, monkeypatch, capfd):
+    """emsar_rsh_read parses the body of a plain rsh in byte ranges on several threads: names, row order (size, first
+    tid, file order), tids, EUMA vectors and 'last single-tid line wins' must be those of the one-thread read."""
+    fx = get_fixture(case)
+    src = os.path.join(fx.dir, "index.rsh")
+    monkeypatch.setenv("EMSAR_HOST_THREADS", "1")
+    want = _rsh_arrays(HL.HostRsh(src))
+    size = os.path.getsize(src)
+    monkeypatch.setenv("EMSAR_HOST_DEBUG", "1")
+    for threads, rb in ((2, size // 5), (5, size // 11), (16, max(20, size // 40)), (64, 17)):
+        monkeypatch.setenv("EMSAR_HOST_THREADS", str(threads))
+        monkeypatch.setenv("EMSAR_HOST_RANGE_BYTES", str(max(rb, 1)))
+        capfd.readouterr()
+        got = _rsh_arrays(HL.HostRsh(src))
+        assert "emsar_rsh_read: 1 part(s)" not in capfd.readouterr().err
+        assert got == want
+    gz = str(tmp_path / "index.rsh.gz")
+    with open(src, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    capfd.readouterr()
+    assert _rsh_arrays(HL.HostRsh(gz)) == want                    # gzip: one part whatever is asked
+    assert "emsar_rsh_read: 1 part(s)" in capfd.readouterr().err
+
+
+def test_rsh_ranges_keep_file_order_semantics(tmp_path, monkeypatch):
+    """Lines whose order matters, spread over many ranges: a transcript with several single-tid lines (the last one
+    wins), several @ lines for one tid (the last name wins), equal (size, first tid) nodes (file order), and the
+    errors of the one-thread read (first bad line in file order, a second header line)."""
+    fx = get_fixture("syn300_se")
+    text = open(os.path.join(fx.dir, "index.rsh")).read().split("\n")
+    hdr = [l for l in text if l.startswith("#")][0]
+    n_tx = int(hdr[1:].split(",")[0]) + 1
+    body = [l for l in text if l and not l.startswith("#")]
+    rng = random.Random(3)
+    extra = []
+    for _ in range(60):
+        t = rng.randrange(n_tx)
+        extra.append("0\t1\t%d\t\t%d,%d,%d," % (t, rng.randrange(900), rng.randrange(900), rng.randrange(900)))
+        extra.append("@%d\tRENAMED%d_%d" % (t, t, rng.randrange(1000)))
+        a = rng.randrange(n_tx - 3)
+        extra.append("0\t2\t%d\t%d,\t%d,%d,%d," % (a, a + 1 + rng.randrange(2), rng.randrange(90), rng.randrange(90), rng.randrange(90)))
+    mains = [l for l in body if not l.startswith("@")] + [e for e in extra if not e.startswith("@")]
+    rng.shuffle(mains)
+    ats = [l for l in body if l.startswith("@")] + [e for e in extra if e.startswith("@")]
+    # renamed @ lines must stay unique as names: the name index maps a name to one tid
+    path = str(tmp_path / "order.rsh")
+    open(path, "w").write("\n".join([hdr] + ats + mains) + "\n")
+    monkeypatch.setenv("EMSAR_HOST_THREADS", "1")
+    want = _rsh_arrays(HL.HostRsh(path))
+    for threads, rb in ((3, 4000), (16, 500), (64, 61)):
+        monkeypatch.setenv("EMSAR_HOST_THREADS", str(threads))
+        monkeypatch.setenv("EMSAR_HOST_RANGE_BYTES", str(rb))
+        assert _rsh_arrays(HL.HostRsh(path)) == want
+    # errors: the first bad line in file order names the error, with any number of ranges
+    bad = [hdr] + ats + mains[:200] + ["7\t2\t%d\t5,\t1,2,3," % (n_tx + 5)] + mains[200:400] + ["9\t3\t1\t2,\t1,2,3,"] + mains[400:] + [hdr]
+    path2 = str(tmp_path / "bad.rsh")
+    open(path2, "w").write("\n".join(bad) + "\n")
+    msgs = []
+    for threads, rb in ((1, 1 << 30), (7, 300)):
+        monkeypatch.setenv("EMSAR_HOST_THREADS", str(threads))
+        monkeypatch.setenv("EMSAR_HOST_RANGE_BYTES", str(rb))
+        with pytest.raises(HL.HostError) as e:
+            HL.HostRsh(path2)
+        msgs.append(str(e.value))
+    assert msgs[0] == msgs[1] and "bad segment line" in msgs[0]
