@@ -1685,10 +1685,24 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
     }
     ctx->layout = layout;
     const size_t T = (size_t)n_tx;
+    const bool dbg = getenv("EMSAR_HIP_DEBUG") != nullptr;
+    const auto tu0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    // the host copy of the CSR kept for the set-resident solver (built per sample: sets depend on which rows carry reads)
+    // is made by a second thread while this one builds the device layout from the same arrays
+    bool copy_failed = false;
+    std::thread csr_copy([&] {
+        try {
+            ctx->h_row_ptr.assign(row_ptr, row_ptr + n_rows + 1);
+            ctx->h_col.assign(col_idx, col_idx + ctx->nnz);
+        } catch (const std::bad_alloc &) { copy_failed = true; }
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{csr_copy};
     try {
         if (layout == EMSAR_LAYOUT_TILED) {
             auto &L = ctx->TL;
             if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows) != 0) return EMSAR_HIP_ERR_ARG;
+            if (dbg) fprintf(stderr, "upload_structure: layout built after %.0f ms\n", since(tu0));
             ctx->n_tiles = (int64_t)L.tiles.size(); ctx->n_slots = L.n_slots(); ctx->n_left = (int64_t)L.left_row.size();
             auto up = [&](void **dp, const void *src, size_t bytes) -> hipError_t {
                 hipError_t e = hipMalloc(dp, std::max<size_t>(bytes, 16));
@@ -1756,13 +1770,14 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
             ctx->bytes_stored = ctx->nnz * 4 + (n_rows + 1) * (ctx->ptr64 ? 8 : 4);
         }
     } catch (const std::bad_alloc &) {
+        csr_copy.join();
         free_structure(ctx);
         return EMSAR_HIP_ERR_OOM;
     }
-    try {   // kept for the set-resident solver, which is built per sample (sets depend on which rows carry reads)
-        ctx->h_row_ptr.assign(row_ptr, row_ptr + n_rows + 1);
-        ctx->h_col.assign(col_idx, col_idx + ctx->nnz);
-    } catch (const std::bad_alloc &) { free_structure(ctx); return EMSAR_HIP_ERR_OOM; }
+    if (dbg) fprintf(stderr, "upload_structure: device copies done after %.0f ms\n", since(tu0));
+    csr_copy.join();
+    if (copy_failed) { free_structure(ctx); return EMSAR_HIP_ERR_OOM; }
+    if (dbg) fprintf(stderr, "upload_structure: host CSR copy joined after %.0f ms\n", since(tu0));
     HIPCHK(hipMalloc(&ctx->d_den, T * 8));
     HIPCHK(hipMalloc(&ctx->d_acc, T * 8));
     for (auto &p : ctx->d_th) HIPCHK(hipMalloc(&p, T * 8));

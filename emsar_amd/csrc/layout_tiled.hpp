@@ -24,10 +24,14 @@
 #include <algorithm>
 #include <thread>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <utility>
 #include <vector>
 
 #include "layout.hpp"
@@ -161,12 +165,54 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     if (!merge_rows) { out.n_rows = n_rows; out.n_tx = n_tx; out.nnz = (int64_t)row_ptr[n_rows]; }
     out.left_ptr.push_back(0);
 
+    const bool dbg_t = getenv("EMSAR_HIP_DEBUG") != nullptr;
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto tp0 = t_now();
     // ---- classify rows; keys of the tiled ones ----
+    // host threads of the builder (fragments below use the same rule); every parallel step gives the result of the
+    // sequential one, so the layout does not depend on the number of threads
+    int n_host = 1;
+    int64_t min_chunk = (int64_t)1 << 16;                 // rows per thread at least
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        n_host = (int)(hw ? std::min(hw, 16u) : 1u);
+        if (n_rows < (int64_t)1 << 16) n_host = 1;
+        if (const char *e = getenv("EMSAR_HOST_THREADS")) { int v = atoi(e); if (v >= 1) { n_host = std::min(v, 64); min_chunk = 16; } }   // tests: threads on small inputs
+    }
+    auto par_ranges = [&](int64_t n, const std::function<void(int, int64_t, int64_t)> &fn) {
+        const int nt = (int)std::min<int64_t>(n_host, std::max<int64_t>(1, n / min_chunk));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(fn, t, n * t / nt, n * (t + 1) / nt);
+        fn(0, 0, n / nt);
+        for (auto &th : pool) th.join();
+        return nt;
+    };
     std::vector<int32_t> mintid((size_t)n_rows, -1);      // the anchor tid of every tiled row (see below)
-    std::vector<int32_t> anchor_tmp;
     bool anchor_median = true;
     if (const char *e = getenv("EMSAR_HIP_TILE_ANCHOR")) anchor_median = atoi(e) != 0;
-    int64_t n_act = 0;
+    // the row's anchor in tid space decides which tile it joins: the MEDIAN id, not the smallest -- a read that also
+    // hits one transcript of another family stays with its own family, and only that one entry is far from the
+    // tile's window (anchored at the minimum, half of such rows landed in the other family's tile with ALL their
+    // in-family ids far: 6.5 M far entries on config 3 instead of 1.6 M)
+    par_ranges(n_rows, [&](int, int64_t lo, int64_t hi) {
+        std::vector<int32_t> tmp;
+        for (int64_t r = lo; r < hi; r++) {
+            const uint64_t b = row_ptr[r], e = row_ptr[r + 1], len = e - b;
+            if (len < 2 || len > (uint64_t)kMaxRowLen) continue;
+            int32_t m;
+            if (anchor_median) {
+                tmp.assign(col_idx + b, col_idx + e);
+                std::nth_element(tmp.begin(), tmp.begin() + (std::ptrdiff_t)(len / 2), tmp.end());
+                m = tmp[(size_t)(len / 2)];
+            } else {
+                m = col_idx[b];
+                for (uint64_t k = b + 1; k < e; k++) m = std::min(m, col_idx[k]);
+            }
+            mintid[(size_t)r] = m;
+        }
+    });
+    std::vector<uint32_t> act;                             // the tiled rows, ascending
     for (int64_t r = 0; r < n_rows; r++) {
         uint64_t b = row_ptr[r], e = row_ptr[r + 1];
         uint64_t len = e - b;
@@ -179,22 +225,9 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             out.left_ptr.push_back((uint64_t)out.left_col.size());
             continue;
         }
-        // the row's anchor in tid space decides which tile it joins: the MEDIAN id, not the smallest -- a read that also
-        // hits one transcript of another family stays with its own family, and only that one entry is far from the
-        // tile's window (anchored at the minimum, half of such rows landed in the other family's tile with ALL their
-        // in-family ids far: 6.5 M far entries on config 3 instead of 1.6 M)
-        int32_t m;
-        if (anchor_median) {
-            anchor_tmp.assign(col_idx + b, col_idx + e);
-            std::nth_element(anchor_tmp.begin(), anchor_tmp.begin() + (std::ptrdiff_t)(len / 2), anchor_tmp.end());
-            m = anchor_tmp[(size_t)(len / 2)];
-        } else {
-            m = col_idx[b];
-            for (uint64_t k = b + 1; k < e; k++) m = std::min(m, col_idx[k]);
-        }
-        mintid[(size_t)r] = m;
-        n_act++;
+        act.push_back((uint32_t)r);
     }
+    const int64_t n_act = (int64_t)act.size();
     // Sort granularity in tid space.  A tile's dictionary must hold a block's tid range plus the rows' reach, so
     // blocks stay small; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
     int32_t block = 512;
@@ -205,23 +238,49 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     if (const char *e = getenv("EMSAR_HIP_TILE_DENSE")) { int v = atoi(e); if (v >= 1 && v <= 64) dense_min = v; }
     bool cut_at_slices = true;
     if (const char *e = getenv("EMSAR_HIP_TILE_CUT")) cut_at_slices = atoi(e) != 0;
+    const auto tp1 = t_now();
     // ---- sort: pass A by anchor tid, pass B by (block, length class); both stable ----
-    std::vector<uint32_t> pa((size_t)n_act), perm((size_t)n_act);
-    {
-        std::vector<uint64_t> cnt((size_t)n_tx + 1, 0);
-        for (int64_t r = 0; r < n_rows; r++) if (mintid[(size_t)r] >= 0) cnt[(size_t)mintid[(size_t)r] + 1]++;
-        for (int32_t t = 0; t < n_tx; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
-        for (int64_t r = 0; r < n_rows; r++) if (mintid[(size_t)r] >= 0) pa[(size_t)cnt[(size_t)mintid[(size_t)r]]++] = (uint32_t)r;
-        int64_t n_blocks = ((int64_t)n_tx + block - 1) / block;
-        std::vector<uint64_t> cnt2((size_t)(n_blocks * kLenClasses) + 1, 0);
-        auto key = [&](uint32_t r) {
-            return (size_t)(mintid[r] / block) * kLenClasses + (size_t)len_class((int64_t)(row_ptr[r + 1] - row_ptr[r]));
+    // A stable counting sort over chunks of the input: one histogram per chunk, offsets ordered (key, chunk), then every
+    // chunk scatters its own rows in order -- the permutation of the sequential sort.
+    auto counting_sort = [&](const std::vector<uint32_t> &in, std::vector<uint32_t> &dst, size_t n_keys, auto key) {
+        const int64_t n = (int64_t)in.size();
+        dst.resize((size_t)n);
+        const int nc = (int)std::min<int64_t>(n_host, std::max<int64_t>(1, n / min_chunk));
+        std::vector<std::vector<uint64_t>> hist((size_t)nc);
+        auto chunk = [&](int c) { return std::make_pair(n * c / nc, n * (c + 1) / nc); };
+        std::vector<std::thread> pool;
+        auto count = [&](int c) {
+            hist[(size_t)c].assign(n_keys, 0);
+            auto [lo, hi] = chunk(c);
+            for (int64_t i = lo; i < hi; i++) hist[(size_t)c][key(in[(size_t)i])]++;
         };
-        for (int64_t i = 0; i < n_act; i++) cnt2[key(pa[(size_t)i]) + 1]++;
-        for (size_t i = 0; i + 1 < cnt2.size(); i++) cnt2[i + 1] += cnt2[i];
-        for (int64_t i = 0; i < n_act; i++) { uint32_t r = pa[(size_t)i]; perm[(size_t)cnt2[key(r)]++] = r; }
+        for (int c = 1; c < nc; c++) pool.emplace_back(count, c);
+        count(0);
+        for (auto &th : pool) th.join();
+        pool.clear();
+        uint64_t run = 0;
+        for (size_t k = 0; k < n_keys; k++)
+            for (int c = 0; c < nc; c++) { const uint64_t h = hist[(size_t)c][k]; hist[(size_t)c][k] = run; run += h; }
+        auto scatter = [&](int c) {
+            auto [lo, hi] = chunk(c);
+            uint64_t *off = hist[(size_t)c].data();
+            for (int64_t i = lo; i < hi; i++) { const uint32_t r = in[(size_t)i]; dst[(size_t)off[key(r)]++] = r; }
+        };
+        for (int c = 1; c < nc; c++) pool.emplace_back(scatter, c);
+        scatter(0);
+        for (auto &th : pool) th.join();
+    };
+    std::vector<uint32_t> pa, perm;
+    {
+        counting_sort(act, pa, (size_t)n_tx, [&](uint32_t r) { return (size_t)mintid[r]; });
+        std::vector<uint32_t>().swap(act);
+        const int64_t n_blocks = ((int64_t)n_tx + block - 1) / block;
+        counting_sort(pa, perm, (size_t)(n_blocks * kLenClasses), [&](uint32_t r) {
+            return (size_t)(mintid[r] / block) * kLenClasses + (size_t)len_class((int64_t)(row_ptr[r + 1] - row_ptr[r]));
+        });
     }
     std::vector<uint32_t>().swap(pa);
+    const auto tp2 = t_now();
 
     // ---- tiles ----
     // The sorted rows are cut into fragments of kFragRows rows; every fragment is tiled on its own (into a private
@@ -412,6 +471,13 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         worker();
         for (auto &th : pool) th.join();
         for (int64_t g = 0; g < n_frag; g++) if (frc[(size_t)g] != 0) return frc[(size_t)g];
+        const auto tp3 = t_now();
+        if (dbg_t) fprintf(stderr, "build_tiled: classify %.0f ms, sort %.0f ms, tiles %.0f ms on %d thread(s)\n", t_ms(tp0, tp1), t_ms(tp1, tp2), t_ms(tp2, tp3), nthr);
+        {
+            size_t nt_ = 0, ns_ = 0, nf_ = 0, nb_ = 0, nc_ = 0, nfar_ = 0;
+            for (const TiledLayout &F : frag) { nt_ += F.tiles.size(); ns_ += F.slot_row.size(); nf_ += F.fwd.size(); nb_ += F.bwd.size(); nc_ += F.coo.size(); nfar_ += F.far_tid.size(); }
+            out.tiles.reserve(nt_); out.slot_row.reserve(ns_); out.fwd.reserve(nf_); out.bwd.reserve(nb_); out.coo.reserve(nc_); out.far_tid.reserve(nfar_);
+        }
         for (int64_t g = 0; g < n_frag; g++) {
             TiledLayout &F = frag[(size_t)g];
             const uint64_t fwd_b = (uint64_t)out.fwd.size() * 4, bwd_b = (uint64_t)out.bwd.size() * 4;
@@ -437,6 +503,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         return w;
     };
     std::stable_sort(out.tiles.begin(), out.tiles.end(), [&](const Tile &a, const Tile &b) { return work(a) > work(b); });
+    if (dbg_t) fprintf(stderr, "build_tiled: total %.0f ms\n", t_ms(tp0, t_now()));
     return 0;
 }
 

@@ -4,10 +4,18 @@
 #include "../emsar_amd/csrc/sets.hpp"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
-int main() {
+static bool same_layout(const emsar::TiledLayout &a, const emsar::TiledLayout &b) {
+    return a.tiles.size() == b.tiles.size() && (a.tiles.empty() || memcmp(a.tiles.data(), b.tiles.data(), a.tiles.size() * sizeof(emsar::Tile)) == 0) &&
+           a.single_row == b.single_row && a.single_tid == b.single_tid && a.slot_row == b.slot_row && a.fwd == b.fwd && a.bwd == b.bwd &&
+           a.coo == b.coo && a.far_tid == b.far_tid && a.left_ptr == b.left_ptr && a.left_col == b.left_col && a.left_row == b.left_row &&
+           a.mem_ptr == b.mem_ptr && a.mem_row == b.mem_row;
+}
+int main(int argc, char **argv) {
     std::mt19937 rng(1);
-    for (int trial = 0; trial < 40; trial++) {
+    const int n_layout = argc > 1 ? atoi(argv[1]) : 40, n_sets = argc > 2 ? atoi(argv[2]) : 60;
+    for (int trial = 0; trial < n_layout; trial++) {
         int n_tx = 50 + rng() % 5000;
         int n_rows = rng() % 20000;
         std::vector<uint64_t> rp(1, 0);
@@ -23,17 +31,22 @@ int main() {
         else if (trial % 4 == 2) setenv("EMSAR_HIP_FRAG_ROWS", "7000", 1);
         else unsetenv("EMSAR_HIP_FRAG_ROWS");
         for (int merge = 0; merge < 2; merge++) {
-            emsar::TiledLayout L;
+            emsar::TiledLayout L, L1;
+            setenv("EMSAR_HOST_THREADS", trial % 2 ? "5" : "16", 1);             // classification, both sorts and the fragments on several threads
             int rc = emsar::build_tiled(n_rows, n_tx, rp.data(), ci.data(), L, merge);
             int ck = rc ? -99 : emsar::check_tiled(L, rp.data(), ci.data());
             if (rc || ck) { printf("FAIL trial %d merge %d rc %d ck %d\n", trial, merge, rc, ck); return 1; }
+            setenv("EMSAR_HOST_THREADS", "1", 1);                                // the layout must not depend on the thread count
+            rc = emsar::build_tiled(n_rows, n_tx, rp.data(), ci.data(), L1, merge);
+            if (rc || !same_layout(L, L1)) { printf("FAIL trial %d merge %d: layout depends on the thread count\n", trial, merge); return 1; }
+            unsetenv("EMSAR_HOST_THREADS");
         }
         emsar::WindowedLayout W;
         int rc = emsar::build_windowed(n_rows, n_tx, rp.data(), ci.data(), 256 << (trial % 5), 4096, W);
         if (rc || emsar::check_windowed(W, rp.data(), ci.data())) { printf("FAIL windowed %d\n", trial); return 1; }
     }
     // set-resident records: sparse family-like matrices (many small sets), weights with zeros, a few huge rows
-    for (int trial = 0; trial < 60; trial++) {
+    for (int trial = 0; trial < n_sets; trial++) {
         int n_tx = 20 + rng() % 6000;
         int n_rows = rng() % 30000;
         int fam = 2 + rng() % (trial % 3 == 0 ? 400 : 12);
