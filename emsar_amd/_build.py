@@ -48,7 +48,8 @@ def _run(cmd, cwd=None):
 def build_hip(force=False):
     src = os.path.join(CSRC, "emsar_hip.hip")
     src2 = os.path.join(CSRC, "collapse.hip")
-    deps = [src, src2, os.path.join(CSRC, "internal.hpp"), os.path.join(CSRC, "layout.hpp"), os.path.join(CSRC, "layout_tiled.hpp"), os.path.join(CSRC, "sets.hpp"), os.path.join(ROOT, "include", "emsar_hip.h")]
+    deps = [src, src2, os.path.join(ROOT, "include", "emsar_hip.h")] + sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))      # layouts, sets, kernels_*.hpp
     if force or _stale(HIP_SO, deps):
         os.makedirs(BUILD, exist_ok=True)
         # compile inside build/ so that -save-temps leaves the .s (register / LDS usage) there

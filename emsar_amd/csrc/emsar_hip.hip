@@ -7,12 +7,15 @@
 // and compute_iEUMA / the TPM + iReadcount arithmetic of print_FPKMfinal (emsar_functions.c:3176-3232).
 //
 // One pass is HBM-bound integer streaming plus FP64 adds: ~2 flop per nonzero -- no MFMA.
-// Kernels:
-//   k_pass_windowed   the hot one: one workgroup per chunk, theta/acc windows in LDS, one lane per row,
-//                     column-major 64-row slices (256 contiguous bytes per wave load)
-//   k_pass_csr        generic fallback on the caller's CSR, one lane per row, FP64 atomics to L2/HBM
-//   k_update          theta' = theta*acc/den, clears acc, max-relative-change reduction
-//   k_update_p2/p3, k_sq_extrap_ll   SQUAREM extrapolation / acceptance entirely on the device (no host round trip)
+// This file: the context, the launch logic (launch_pass, enqueue_cycles, the set solver's driver) and the C ABI.
+// Kernels (one translation unit, included below):
+//   kernels_tiled.hpp     k_pass_tiled / k_pass_tiled_multi<2>   the hot ones: one workgroup per tile (or pair of tiles) of the
+//                         TILED layout, dictionary of theta/acc in LDS, 10-bit ids, per-slice transposed index
+//   kernels_windowed.hpp  k_pass_windowed, k_pass_csr            the WINDOWED layout and the caller's CSR (layouts 2 and 1)
+//   kernels_vector.hpp    k_update, k_update_p2/p3, k_sq_extrap_ll (SQUAREM extrapolation / acceptance on the device),
+//                         k_normalise, k_adj_euma, small reductions
+//   kernels_sets.hpp      k_solve_sets                           one workgroup solves one connected set out of LDS
+//   collapse.hip          read-level rows -> weighted segments (own translation unit)
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -30,1229 +33,11 @@
 #include "sets.hpp"
 #include "internal.hpp"
 
-namespace {
-
-using emsar::Chunk;
-using emsar::Tile;
-constexpr int kPassThreads = 512;     // 8 waves per workgroup
-constexpr int kDefaultWindow = 4096;  // 2 x 32 KiB of LDS per workgroup -> 2 workgroups per CU
-constexpr int64_t kChunkEntries = 65536;
-
-// ------------------------------------------------------------------------------------------------
-// device scalars of one solve (lives in HBM, polled by the host every check_every cycles)
-// ------------------------------------------------------------------------------------------------
-struct Scal {
-    double ll[4];                 // sum_c R_c log S_c at the input of pass 0/1/2 of the cycle; [3] scratch
-    double sr2, sv2, pen1, penx;  // SQUAREM norms, sum theta*den of th1 and of the extrapolated point
-    double stepmax, s_used;
-    unsigned long long delta_bits;  // max_t |dtheta|/(theta+floor) as IEEE bits (non-negative -> integer max)
-    unsigned long long delta1_bits; // the same, frozen after the first (plain) pass of a SQUAREM cycle
-    int32_t accepted, rejected;
-    double sum_a, sum_b;          // generic reductions (normalise)
-    long long passes;             // EM passes enqueued before the current cycle (k_cycle_begin keeps it: the cycle may replay from a hipGraph)
-    double abs_step_cur;          // emsar_em_params.abs_step scaled to the pass count of the current cycle (0 = rule off)
-};
-
-__device__ __forceinline__ void atomic_add_f64(double *p, double v) {
-    // gfx950: global_atomic_add_f64 / ds_add_f64 (no CAS loop; compiled with -munsafe-fp-atomics)
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void lds_add_f64(double *p, double v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-template <int THREADS>
-__device__ __forceinline__ double block_sum(double v, double *red /* THREADS/64 doubles of LDS */) {
-    v = wave_sum(v);
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    double t = 0;
-    if (threadIdx.x == 0)
-        for (int i = 0; i < THREADS / 64; i++) t += red[i];
-    return t;  // valid in thread 0
-}
-
-enum PassMode { MODE_EM = 0, MODE_EM_LL = 1, MODE_SCATTER = 2 };
-
-// ------------------------------------------------------------------------------------------------
-// k_pass_windowed: one EM pass (or a plain row-value scatter) over the WINDOWED layout.
-//   chunks[blockIdx.x]  -> slices [slice_begin, +n_slices), LDS window [lo, lo+width)
-//   a wave owns one 256-row slice at a time; lane l handles rows 4l..4l+3 of it; the j-th tids of those four
-//   rows are ONE int4 at ent[slice_off + j*256 + 4l]  (1 KiB contiguous per wave load)
-// Up to 8 loads (8 KiB per wave) are issued before the first use, the tids then stay in registers for both
-// the E-step sums and the M-step adds; rows longer than 8 are streamed in segments of 8 and re-read (L2) for
-// the adds.
-// HBM traffic per pass: ent once (4 B per stored slot), slice_off (8 B per 256 rows), optional row weights;
-// theta window loads and acc window flushes are O(n_tx + chunks*family) and stay in L2.
-// ------------------------------------------------------------------------------------------------
-constexpr int kSeg = 8;  // int4 loads in flight per lane
-
-struct Window {
-    const double *th_w; double *acc_w; const double *theta; double *acc; int lo; unsigned width;
-    __device__ __forceinline__ double get(int t) const {
-        unsigned d = (unsigned)(t - lo);
-        return d < width ? th_w[d] : theta[t];
-    }
-    __device__ __forceinline__ void add(int t, double v) const {
-        unsigned d = (unsigned)(t - lo);
-        if (d < width) lds_add_f64(&acc_w[d], v);
-        else atomic_add_f64(&acc[t], v);
-    }
-};
-
-// The segment length n (1..8) is wave-uniform; each length gets its own straight-line code so that all n
-// loads are issued back to back (n KiB in flight per wave) with no control flow between them.
-template <int N>
-__device__ __forceinline__ void load_n(int4 (&q)[N], const int4 *e) {
-#pragma unroll
-    for (int j = 0; j < N; j++) q[j] = e[(size_t)j * 64];
-}
-
-template <int N>
-__device__ __forceinline__ void sum_n(const int4 (&q)[N], const Window &W, double (&S)[4]) {
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        int4 t = q[j];
-        if (t.x >= 0) S[0] += W.get(t.x);
-        if (t.y >= 0) S[1] += W.get(t.y);
-        if (t.z >= 0) S[2] += W.get(t.z);
-        if (t.w >= 0) S[3] += W.get(t.w);
-    }
-}
-
-// M-step adds of one segment.  The four rows of a lane are neighbours in the sorted order and often carry
-// the same tid in column j: equal neighbours are merged in registers first, so that one LDS atomic carries
-// up to four contributions (an LDS f64 atomic costs ~6 cycles per extra lane on the same address).
-template <int N>
-__device__ __forceinline__ void add_n(const int4 (&q)[N], const Window &W, const double (&w)[4]) {
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        int4 t = q[j];
-        double v0 = t.x >= 0 ? w[0] : 0.0, v1 = t.y >= 0 ? w[1] : 0.0;
-        double v2 = t.z >= 0 ? w[2] : 0.0, v3 = t.w >= 0 ? w[3] : 0.0;
-        if (t.y == t.x) { v1 += v0; v0 = 0.0; }
-        if (t.z == t.y) { v2 += v1; v1 = 0.0; }
-        if (t.w == t.z) { v3 += v2; v2 = 0.0; }
-        if (v0 != 0.0) W.add(t.x, v0);
-        if (v1 != 0.0) W.add(t.y, v1);
-        if (v2 != 0.0) W.add(t.z, v2);
-        if (v3 != 0.0) W.add(t.w, v3);
-    }
-}
-
-template <bool WEIGHTED, int MODE>
-__device__ __forceinline__ void row_weights(const double (&S)[4], const int32_t *wgt, uint64_t row0, double (&w)[4], double &ll) {
-    double r[4] = {1.0, 1.0, 1.0, 1.0};
-    if (WEIGHTED) {
-        int4 rw = *reinterpret_cast<const int4 *>(wgt + row0);
-        r[0] = rw.x; r[1] = rw.y; r[2] = rw.z; r[3] = rw.w;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        bool live = (S[i] > 0.0) && (r[i] > 0.0);
-        w[i] = live ? r[i] / S[i] : 0.0;
-        if (MODE == MODE_EM_LL && live) ll += r[i] * log(S[i]);
-    }
-}
-
-__device__ __forceinline__ void scatter_weights(const double *rowval, uint64_t row0, double (&w)[4]) {
-    const double2 *rv = reinterpret_cast<const double2 *>(rowval + row0);
-    double2 a = rv[0], b = rv[1];
-    w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
-}
-
-// A slice whose rows have at most 8 tids: all N loads (N KiB per wave) are issued back to back, the tids stay
-// in registers for the E-step sums and the M-step adds.  One straight-line instance per N.
-template <int N, bool WEIGHTED, int MODE>
-__device__ __forceinline__ void slice_short(const int4 *e, uint64_t row0, const Window &W, const int32_t *wgt,
-                                            const double *rowval, double &ll) {
-    int4 q[N];
-    double w[4];
-    load_n<N>(q, e);
-    if (MODE == MODE_SCATTER) {
-        scatter_weights(rowval, row0, w);
-    } else {
-        double S[4] = {0.0, 0.0, 0.0, 0.0};
-        sum_n<N>(q, W, S);
-        row_weights<WEIGHTED, MODE>(S, wgt, row0, w, ll);
-    }
-    add_n<N>(q, W, w);
-}
-
-// Rows with more than 8 tids: streamed in segments of 8 loads for the sums, re-read (L2) for the adds.
-template <bool WEIGHTED, int MODE>
-__device__ __forceinline__ void slice_long(const int4 *e, int k, uint64_t row0, const Window &W, const int32_t *wgt,
-                                           const double *rowval, double &ll) {
-    double w[4];
-    const int nfull = k / kSeg, rem = k % kSeg;
-    if (MODE == MODE_SCATTER) {
-        scatter_weights(rowval, row0, w);
-    } else {
-        double S[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int g = 0; g < nfull; g++) {
-            int4 q[kSeg];
-            load_n<kSeg>(q, e + (size_t)g * kSeg * 64);
-            sum_n<kSeg>(q, W, S);
-        }
-        for (int j = nfull * kSeg; j < k; j++) {
-            int4 q[1];
-            load_n<1>(q, e + (size_t)j * 64);
-            sum_n<1>(q, W, S);
-        }
-        row_weights<WEIGHTED, MODE>(S, wgt, row0, w, ll);
-    }
-    for (int g = 0; g < nfull; g++) {
-        int4 q[kSeg];
-        load_n<kSeg>(q, e + (size_t)g * kSeg * 64);
-        add_n<kSeg>(q, W, w);
-    }
-    for (int j = nfull * kSeg; j < k; j++) {
-        int4 q[1];
-        load_n<1>(q, e + (size_t)j * 64);
-        add_n<1>(q, W, w);
-    }
-    (void)rem;
-}
-
-template <int THREADS, bool WEIGHTED, int MODE>
-__global__ __launch_bounds__(THREADS) void k_pass_windowed(const Chunk *__restrict__ chunks,
-                                                           const uint64_t *__restrict__ slice_off,
-                                                           const int32_t *__restrict__ ent,
-                                                           const int32_t *__restrict__ wgt,   // sorted rows, padded
-                                                           const double *__restrict__ rowval, // MODE_SCATTER
-                                                           const double *__restrict__ theta,
-                                                           double *__restrict__ acc, double *__restrict__ ll_out,
-                                                           int window) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *th_w = lds;            // [window]
-    double *acc_w = lds + window;  // [window]
-    __shared__ double red[THREADS / 64];
-
-    const Chunk c = chunks[blockIdx.x];
-    const int lo = c.lo, width = c.width;
-    for (int i = threadIdx.x; i < width; i += THREADS) {
-        if (MODE != MODE_SCATTER) th_w[i] = theta[lo + i];
-        acc_w[i] = 0.0;
-    }
-    __syncthreads();
-    const Window W{th_w, acc_w, theta, acc, lo, (unsigned)width};
-
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // keep slice bookkeeping in SGPRs
-    double ll = 0.0;
-    for (uint32_t s = wave; s < c.n_slices; s += THREADS / 64) {
-        const uint32_t gs = c.slice_begin + s;
-        const uint64_t off = slice_off[gs];
-        const int k = (int)((slice_off[gs + 1] - off) >> 8);
-        const int4 *e = reinterpret_cast<const int4 *>(ent + off) + lane;
-        const uint64_t row0 = (uint64_t)gs * 256 + 4 * lane;
-#define EMSAR_SHORT(NN) case NN: slice_short<NN, WEIGHTED, MODE>(e, row0, W, wgt, rowval, ll); break;
-        switch (k) {
-            EMSAR_SHORT(1) EMSAR_SHORT(2) EMSAR_SHORT(3) EMSAR_SHORT(4)
-            EMSAR_SHORT(5) EMSAR_SHORT(6) EMSAR_SHORT(7) EMSAR_SHORT(8)
-            default: slice_long<WEIGHTED, MODE>(e, k, row0, W, wgt, rowval, ll); break;
-        }
-#undef EMSAR_SHORT
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < width; i += THREADS) {
-        double v = acc_w[i];
-        if (v != 0.0) atomic_add_f64(&acc[lo + i], v);
-    }
-    if (MODE == MODE_EM_LL) {
-        double t = block_sum<THREADS>(ll, red);
-        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_pass_tiled: one EM pass over the TILED layout (layout_tiled.hpp).  One workgroup = 4 waves = the 4 slices of a tile.
-//   phase 0  every global load the wave needs first is issued at once (dictionary theta values, 8 forward columns,
-//            8 backward segments); dictionary: th_w[d] = theta[tid(d)], acc_w[d] = 0, zero slots; barrier
-//   phase E  the wave owns one slice (768 rows; lane l holds rows 64*i + l, i < 12): S_r = sum th_w[id]  (LDS reads only, 10-bit ids,
-//            padding reads the zero slot: no branches), w_r = R_r / S_r -> the wave's own 6 KiB of LDS
-//   phase M  the SAME wave walks the transposed index of its rows: a lane's segments (column id + 11 row ids) are
-//            consecutive in column order; it gathers w_r from LDS into a register sum and adds it to acc_w when the
-//            column changes; tiny columns via a COO list.  No barrier between E and M.
-//   phase F  barrier; non-zero dictionary slots are flushed with one global FP64 atomic each
-// HBM traffic: 10 bits per forward slot + 128 bits per 11 backward entries -- no row_ptr, no 32-bit tids.
-// ------------------------------------------------------------------------------------------------
-constexpr int kTiledThreads = 256;                       // 4 wavefronts = 4 slices
-constexpr int kRPL = emsar::kRowsPerLane;                 // 12 rows per lane = twelve 10-bit ids per int4
-constexpr int kTiledWr = emsar::kTileSliceRows + 8;       // w_r of one slice (768) + the zero padding row
-constexpr int kTiledDictPad = emsar::kTileDict + 1;       // 960 slots incl. the zero slot
-constexpr int kTiledLdsDoubles = 2 * kTiledDictPad + emsar::kTileSlices * kTiledWr;   // 40,192 B: 4 workgroups per CU
-
-__device__ __forceinline__ double lds_at(const double *base, unsigned byte_off) {
-    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
-}
-// field f (0,1,2) of a packed dword -> LDS byte offset of the double it names
-__device__ __forceinline__ unsigned id_off(unsigned dword, int f) { return ((dword >> (10 * f)) & 0x3FFu) << 3; }
-
-// 8 independent 16-byte loads; positions beyond n repeat position n-1 (an L1 hit) so that there is no control flow
-// between the loads and all of them are in flight together
-__device__ __forceinline__ void load8_clamped(int4 (&q)[8], const int4 *e, int n) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) q[j] = e[(size_t)(j < n ? j : n - 1) * 64];
-}
-
-// LDS gather of the double named by 10-bit field F of a packed dword: two VALU instructions per entry
-// (v_bfe_u32 + v_lshl_add_u32 with the region's LDS byte address as the scalar addend) instead of the shift / and /
-// add-base triple hipcc emits for the C expression -- the E- and M-steps are bound by instruction issue
-// (4 cycles per wave64 instruction on a 16-lane SIMD), not by LDS bandwidth.
-typedef __attribute__((address_space(3))) const double lds_cdouble;
-__device__ __forceinline__ unsigned lds_byte_addr(const void *p) { return (unsigned)(uintptr_t)p; }   // low half of a flat LDS address
-template <int F>
-__device__ __forceinline__ unsigned lds_id_addr(unsigned dword, unsigned base /* wave-uniform */) {
-    // inline asm: hipcc rewrites the C expression (and the ubfe intrinsic) back into shift + and + add
-    unsigned a;   // one statement: hipcc pads a nop between two dependent asm statements
-    asm("v_bfe_u32 %0, %1, %2, 10\n\tv_lshl_add_u32 %0, %0, 3, %3" : "=v"(a) : "v"(dword), "i"(10 * F), "s"(base));
-    return a;
-}
-__device__ __forceinline__ double lds_ld(unsigned a) { return *reinterpret_cast<lds_cdouble *>(a); }
-// the LDS byte addresses of 6 of the 12 ids of one int4 (H = 0: fields of .x .y, H = 1: of .z .w).  Addresses first,
-// then the loads back to back, then the adds: the asm statements would otherwise serialise address -> load -> wait ->
-// add per entry.  BATCH = 12 keeps a whole int4 in flight (36 temporaries), BATCH = 6 half of it (18).
-template <int H>
-__device__ __forceinline__ void lds_addr6(const int4 t, unsigned base, unsigned (&a)[6]) {
-    const unsigned d0 = (unsigned)(H ? t.z : t.x), d1 = (unsigned)(H ? t.w : t.y);
-    a[0] = lds_id_addr<0>(d0, base); a[1] = lds_id_addr<1>(d0, base); a[2] = lds_id_addr<2>(d0, base);
-    a[3] = lds_id_addr<0>(d1, base); a[4] = lds_id_addr<1>(d1, base); a[5] = lds_id_addr<2>(d1, base);
-}
-
-// E-step sums of up to 8 forward columns held in registers (n is wave-uniform); one int4 = this lane's 12 rows
-template <int BATCH = 12>
-__device__ __forceinline__ void fwd_sum_regs(const int4 (&q)[8], int n, unsigned th_base, double (&S)[kRPL]) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (j < n) {
-            if (BATCH == 12) {
-                unsigned a0[6], a1[6];
-                double v[12];
-                lds_addr6<0>(q[j], th_base, a0); lds_addr6<1>(q[j], th_base, a1);
-#pragma unroll
-                for (int i = 0; i < 6; i++) { v[i] = lds_ld(a0[i]); }
-#pragma unroll
-                for (int i = 0; i < 6; i++) { v[6 + i] = lds_ld(a1[i]); }
-#pragma unroll
-                for (int i = 0; i < 12; i++) S[i] += v[i];
-            } else {
-                unsigned a[6];
-                double v[6];
-                lds_addr6<0>(q[j], th_base, a);
-#pragma unroll
-                for (int i = 0; i < 6; i++) v[i] = lds_ld(a[i]);
-#pragma unroll
-                for (int i = 0; i < 6; i++) S[i] += v[i];
-                lds_addr6<1>(q[j], th_base, a);
-#pragma unroll
-                for (int i = 0; i < 6; i++) v[i] = lds_ld(a[i]);
-#pragma unroll
-                for (int i = 0; i < 6; i++) S[6 + i] += v[i];
-            }
-        }
-    }
-}
-
-// M-step of up to 8 backward segments of one lane ({column, 11 row ids} each).  A lane's segments are consecutive
-// in column order: the running sum stays in a register and goes to the LDS accumulator when the column changes.
-template <int BATCH = 12>
-__device__ __forceinline__ void bwd_sum_regs(const int4 (&q)[8], int n, unsigned ws_base, double *acc_w, unsigned &cur, double &part) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (j < n) {
-            const unsigned col = id_off((unsigned)q[j].x, 0);
-            double sum;
-            if (BATCH == 12) {
-                unsigned a0[6], a1[6];
-                double v[12];
-                lds_addr6<0>(q[j], ws_base, a0); lds_addr6<1>(q[j], ws_base, a1);
-#pragma unroll
-                for (int i = 1; i < 6; i++) v[i] = lds_ld(a0[i]);
-#pragma unroll
-                for (int i = 0; i < 6; i++) v[6 + i] = lds_ld(a1[i]);
-                double s0 = v[1] + v[2], s1 = v[3] + v[4], s2 = v[5] + v[6], s3 = v[7] + v[8];
-                s0 += v[9]; s1 += v[10]; s2 += v[11];
-                sum = (s0 + s1) + (s2 + s3);
-            } else {
-                unsigned a[6];
-                double v[6];
-                lds_addr6<0>(q[j], ws_base, a);
-#pragma unroll
-                for (int i = 1; i < 6; i++) v[i] = lds_ld(a[i]);
-                double s0 = v[1] + v[2], s1 = v[3] + v[4];
-                s0 += v[5];
-                lds_addr6<1>(q[j], ws_base, a);
-#pragma unroll
-                for (int i = 0; i < 6; i++) v[i] = lds_ld(a[i]);
-                s0 += v[0]; s1 += v[1];
-                double s2 = v[2] + v[3], s3 = v[4] + v[5];
-                sum = (s0 + s1) + (s2 + s3);
-            }
-            if (col != cur) {
-                if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
-                cur = col; part = 0.0;
-            }
-            part += sum;
-        }
-    }
-}
-
-// In-kernel stamps (diagnostic instance only, STAMP=true; never the timed kernel): s_memtime per phase and wave,
-// written to a slot of its own that no other code reads.
-__device__ __forceinline__ unsigned long long stamp_now() {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
-
-// sum_i log S_i over a lane's kRPL unweighted rows (S_i <= 0: row outside F or padding, no term) with two logs instead of
-// twelve: log of the product of six row sums.  A product that leaves [1e-280, 1e280] (components decayed towards the
-// boundary) falls back to the per-row logs.  The f64 log is ~40 VALU instructions: 19 % of a likelihood pass on config 3.
-template <int N>
-__device__ __forceinline__ double sum_log_rows(const double (&S)[N]) {
-    static_assert(N % 6 == 0, "rows per lane");
-    double ll = 0.0;
-#pragma unroll
-    for (int g = 0; g < N; g += 6) {
-        double p = 1.0;
-#pragma unroll
-        for (int i = g; i < g + 6; i++) p *= S[i] > 0.0 ? S[i] : 1.0;
-        if (p > 1e-280 && p < 1e280) ll += log(p);
-        else {
-#pragma unroll
-            for (int i = g; i < g + 6; i++) if (S[i] > 0.0) ll += log(S[i]);
-        }
-    }
-    return ll;
-}
-
-template <bool WEIGHTED, int MODE, bool STAMP = false>
-__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__restrict__ tiles, const uint32_t *__restrict__ fwd,
-                                                              const uint32_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
-                                                              const int32_t *__restrict__ far_tid,
-                                                              const int32_t *__restrict__ wgt,    // per row slot
-                                                              const double *__restrict__ rowval,  // per row slot (MODE_SCATTER)
-                                                              const double *__restrict__ theta, double *__restrict__ acc,
-                                                              double *__restrict__ ll_out, unsigned long long *stamps = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *th_w = lds;                     // [960]
-    double *acc_w = lds + kTiledDictPad;    // [960]
-    __shared__ double red[kTiledThreads / 64];
-    unsigned long long ts[6];
-    if (STAMP) ts[0] = stamp_now();
-
-    const Tile T = tiles[blockIdx.x];
-    const int nd = (int)T.near_n + (int)T.far_n;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool has_slice = wave < (int)T.n_slices;
-    double *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;     // this wave's row weights [768] + zero row
-    const unsigned th_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(th_w));
-    const unsigned ws_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(w_s));
-
-    // ---- issue every global load this wave needs first, in the order of use: dictionary values, 8 forward columns,
-    //      8 backward segments.  One HBM round trip per tile; the rest of the pass touches LDS only.
-    double thv[4];
-    int tid_d[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        thv[i] = 0.0; tid_d[i] = -1;
-        if (d < nd) {
-            tid_d[i] = d < (int)T.near_n ? T.lo + d : far_tid[T.far_off + (d - (int)T.near_n)];
-            if (MODE != MODE_SCATTER) thv[i] = theta[tid_d[i]];
-        }
-    }
-    int4 A[8], B[8];
-    const int4 *e = nullptr, *b = nullptr;
-    int k = 0, m = 0;
-    unsigned coo_base = T.coo_off, coo_n = 0;
-    if (has_slice) {
-        unsigned foff = 0, boff = 0;                 // KiB units (256 dwords) from the tile's bases
-#pragma unroll
-        for (int s = 0; s < emsar::kTileSlices; s++) {
-            if (s < wave) { foff += T.k[s]; boff += T.m[s]; coo_base += T.coo_n[s]; }
-            if (s == wave) { k = T.k[s]; m = T.m[s]; coo_n = T.coo_n[s]; }
-        }
-        // everything above is wave-uniform; say so, or the loops below are compiled as divergent code
-        k = __builtin_amdgcn_readfirstlane(k); m = __builtin_amdgcn_readfirstlane(m);
-        coo_n = __builtin_amdgcn_readfirstlane(coo_n); coo_base = __builtin_amdgcn_readfirstlane(coo_base);
-        foff = __builtin_amdgcn_readfirstlane(foff); boff = __builtin_amdgcn_readfirstlane(boff);
-        e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 4 + (size_t)foff * 256) + lane;
-        b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 4 + (size_t)boff * 256) + lane;
-        if (MODE != MODE_SCATTER) load8_clamped(A, e, k < 8 ? k : 8);
-        if (m > 0) load8_clamped(B, b, m < 8 ? m : 8);
-    }
-    // ---- phase 0: dictionary into LDS (slot nd is the zero slot) ----
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        if (d <= nd) { th_w[d] = thv[i]; acc_w[d] = 0.0; }
-    }
-    if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;      // padding row of this wave's slice
-    if (STAMP) ts[1] = stamp_now();
-    __syncthreads();
-    if (STAMP) ts[2] = stamp_now();
-
-    double ll = 0.0;
-    if (has_slice) {
-        // ---- E: row sums of this wave's 768 rows ----
-        // row i of lane l is slot 64*i + l of the slice: the lanes of one gather hold consecutive sorted rows
-        const size_t slot0 = (size_t)T.row_base + (size_t)wave * emsar::kTileSliceRows + lane;
-        double w[kRPL];
-        if (MODE == MODE_SCATTER) {
-#pragma unroll
-            for (int i = 0; i < kRPL; i++) w[i] = rowval[slot0 + 64 * i];
-        } else {
-            double S[kRPL];
-#pragma unroll
-            for (int i = 0; i < kRPL; i++) S[i] = 0.0;
-            for (int j0 = 0; j0 < k; j0 += 8) {
-                const int n0 = k - j0 < 8 ? k - j0 : 8;
-                if (j0) load8_clamped(A, e + (size_t)j0 * 64, n0);
-                fwd_sum_regs(A, n0, th_base, S);
-            }
-            double r[kRPL];
-#pragma unroll
-            for (int i = 0; i < kRPL; i++) r[i] = 1.0;
-            if (WEIGHTED) {
-#pragma unroll
-                for (int i = 0; i < kRPL; i++) r[i] = (double)wgt[slot0 + 64 * i];
-            }
-#pragma unroll
-            for (int i = 0; i < kRPL; i++) {
-                bool live = (S[i] > 0.0) && (r[i] > 0.0);
-                w[i] = live ? r[i] / S[i] : 0.0;
-                if (MODE == MODE_EM_LL && WEIGHTED && live) ll += r[i] * log(S[i]);
-            }
-            if (MODE == MODE_EM_LL && !WEIGHTED) ll += sum_log_rows(S);
-        }
-#pragma unroll
-        for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = w[i];
-        // the M-step below reads rows written by OTHER lanes of this same wave: DS operations of one wave execute in
-        // order, so only the compiler has to be kept from moving the reads up
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (STAMP) ts[3] = stamp_now();
-        // ---- M: column sums over the same 768 rows, through the slice's transposed index ----
-        unsigned cur = 0xFFFFFFFFu;
-        double part = 0.0;
-        for (int j0 = 0; j0 < m; j0 += 8) {
-            const int n0 = m - j0 < 8 ? m - j0 : 8;
-            if (j0) load8_clamped(B, b + (size_t)j0 * 64, n0);
-            bwd_sum_regs(B, n0, ws_base, acc_w, cur, part);
-        }
-        if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
-        for (unsigned q = lane; q < coo_n; q += 64) {
-            const unsigned p = coo[coo_base + q];
-            const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
-            if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + ((p >> 16) << 3)), v);
-        }
-    } else if (STAMP) ts[3] = stamp_now();
-    if (STAMP) ts[4] = stamp_now();
-    __syncthreads();
-    if (STAMP) ts[5] = stamp_now();
-    // ---- F: flush the dictionary ----
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        if (d < nd) {
-            const double v = acc_w[d];
-            if (v != 0.0) atomic_add_f64(&acc[tid_d[i]], v);
-        }
-    }
-    if (STAMP && lane == 0) {   // [tile][wave][5 phases]: issue+dictionary, barrier, E, M, barrier
-        for (int i = 0; i < 5; i++) stamps[((size_t)blockIdx.x * (kTiledThreads / 64) + wave) * 8 + i] = ts[i + 1] - ts[i];
-    }
-    if (MODE == MODE_EM_LL) {
-        double t = block_sum<kTiledThreads>(ll, red);
-        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_pass_tiled_multi: the same pass, N tiles per workgroup, software-pipelined by hand.  In k_pass_tiled a wave has
-// loads in flight only at its start (~20 % of its life); with four workgroups per CU there is often nobody loading and
-// the CU's share of HBM idles.  Here the forward registers are refilled with the next tile's columns as soon as the
-// E-step has consumed them, the backward registers after the M-step, and the next dictionary is requested before the
-// M-step: the next tile's HBM round trip hides behind this tile's LDS work.  Measured on config 3: N = 2 0.218 ms,
-// N = 3 0.224, N = 4 0.242 (fewer, longer workgroups: the tail grows), a persistent loop 0.251 (hipcc spills the
-// loop-carried register arrays); one tile per workgroup 0.225.
-// ------------------------------------------------------------------------------------------------
-struct TileWave {           // what one wave needs to know about its slice of a tile (all wave-uniform but e/b)
-    const int4 *e, *b;
-    int k, m, nd;
-    unsigned coo_base, coo_n;
-    bool has_slice;
-};
-__device__ __forceinline__ TileWave tile_wave(const Tile &T, int wave, int lane, const uint32_t *fwd, const uint32_t *bwd) {
-    TileWave W;
-    W.nd = (int)T.near_n + (int)T.far_n;
-    W.has_slice = wave < (int)T.n_slices;
-    W.e = nullptr; W.b = nullptr; W.k = 0; W.m = 0; W.coo_base = T.coo_off; W.coo_n = 0;
-    if (W.has_slice) {
-        unsigned foff = 0, boff = 0;
-        int k = 0, m = 0; unsigned cn = 0, cb = T.coo_off;
-#pragma unroll
-        for (int s = 0; s < emsar::kTileSlices; s++) {
-            if (s < wave) { foff += T.k[s]; boff += T.m[s]; cb += T.coo_n[s]; }
-            if (s == wave) { k = T.k[s]; m = T.m[s]; cn = T.coo_n[s]; }
-        }
-        W.k = __builtin_amdgcn_readfirstlane(k); W.m = __builtin_amdgcn_readfirstlane(m);
-        W.coo_n = __builtin_amdgcn_readfirstlane(cn); W.coo_base = __builtin_amdgcn_readfirstlane(cb);
-        foff = __builtin_amdgcn_readfirstlane(foff); boff = __builtin_amdgcn_readfirstlane(boff);
-        W.e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 4 + (size_t)foff * 256) + lane;
-        W.b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 4 + (size_t)boff * 256) + lane;
-    }
-    return W;
-}
-__device__ __forceinline__ void tile_dict_issue(const Tile &T, int nd, const int32_t *far_tid, const double *theta, double (&thv)[4], int (&tid_d)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        thv[i] = 0.0; tid_d[i] = -1;
-        if (d < nd) {
-            tid_d[i] = d < (int)T.near_n ? T.lo + d : far_tid[T.far_off + (d - (int)T.near_n)];
-            thv[i] = theta[tid_d[i]];
-        }
-    }
-}
-__device__ __forceinline__ void tile_dict_store(int nd, const double (&thv)[4], double *th_w, double *acc_w) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        if (d <= nd) { th_w[d] = thv[i]; acc_w[d] = 0.0; }
-    }
-}
-template <bool WEIGHTED, int MODE>
-__device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], size_t slot0, const int32_t *wgt, const double *th_w, double *w_s,
-                                            int lane, double &ll) {
-    const unsigned th_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(th_w));
-    double S[kRPL], w[kRPL], r[kRPL];
-#pragma unroll
-    for (int i = 0; i < kRPL; i++) { S[i] = 0.0; r[i] = 1.0; }
-    for (int j0 = 0; j0 < W.k; j0 += 8) {
-        const int n0 = W.k - j0 < 8 ? W.k - j0 : 8;
-        if (j0) load8_clamped(A, W.e + (size_t)j0 * 64, n0);
-        fwd_sum_regs<6>(A, n0, th_base, S);
-    }
-    if (WEIGHTED) {
-#pragma unroll
-        for (int i = 0; i < kRPL; i++) r[i] = (double)wgt[slot0 + 64 * i];
-    }
-#pragma unroll
-    for (int i = 0; i < kRPL; i++) {
-        bool live = (S[i] > 0.0) && (r[i] > 0.0);
-        w[i] = live ? r[i] / S[i] : 0.0;
-        if (MODE == MODE_EM_LL && WEIGHTED && live) ll += r[i] * log(S[i]);
-    }
-    if (MODE == MODE_EM_LL && !WEIGHTED) ll += sum_log_rows(S);
-#pragma unroll
-    for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = w[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], const uint32_t *coo, const double *w_s, double *acc_w, int lane) {
-    const unsigned ws_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(w_s));
-    unsigned cur = 0xFFFFFFFFu;
-    double part = 0.0;
-    for (int j0 = 0; j0 < W.m; j0 += 8) {
-        const int n0 = W.m - j0 < 8 ? W.m - j0 : 8;
-        if (j0) load8_clamped(B, W.b + (size_t)j0 * 64, n0);
-        bwd_sum_regs<6>(B, n0, ws_base, acc_w, cur, part);
-    }
-    if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
-    for (unsigned q = lane; q < W.coo_n; q += 64) {
-        const unsigned p = coo[W.coo_base + q];
-        const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
-        if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + ((p >> 16) << 3)), v);
-    }
-}
-__device__ __forceinline__ void tile_flush(int nd, const int (&tid_d)[4], const double *acc_w, double *acc) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        if (d < nd) {
-            const double v = acc_w[d];
-            if (v != 0.0) atomic_add_f64(&acc[tid_d[i]], v);
-        }
-    }
-}
-
-struct TileEnv {            // per-launch constants of the multi-tile kernel
-    const Tile *tiles; int n_tiles, stride;
-    const uint32_t *fwd, *bwd, *coo; const int32_t *far_tid, *wgt; const double *theta; double *acc;
-    double *th_w, *acc_w, *w_s; int lane, wave;
-};
-// stage I of N: tile `it` is in the registers (A, B in flight or landed, dictionary values in thv); while it is being
-// worked on, tile it + stride is requested into the registers as they fall free.  Straight-line code, no loop: hipcc
-// keeps loop-carried register arrays of this size in scratch.
-template <bool WEIGHTED, int MODE, int I, int N>
-__device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const Tile &T, const TileWave &W, int4 (&A)[8], int4 (&B)[8],
-                                            double (&thv)[4], const int (&tid)[4], double &ll) {
-    // a thread rewrites only the dictionary slots it flushed at the end of the previous stage
-    tile_dict_store(W.nd, thv, V.th_w, V.acc_w);
-    const int in = it + V.stride;
-    const bool has_next = (I + 1 < N) && in < V.n_tiles;
-    const Tile Tn = V.tiles[has_next ? in : it];
-    __syncthreads();
-    if (W.has_slice)
-        tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)V.wave * emsar::kTileSliceRows + V.lane, V.wgt, V.th_w, V.w_s, V.lane, ll);
-    const TileWave Wn = tile_wave(Tn, V.wave, V.lane, V.fwd, V.bwd);
-    int tidn[4] = {-1, -1, -1, -1};
-    if (has_next) {
-        if (Wn.has_slice) load8_clamped(A, Wn.e, Wn.k < 8 ? Wn.k : 8);
-        tile_dict_issue(Tn, Wn.nd, V.far_tid, V.theta, thv, tidn);
-    }
-    if (W.has_slice) tile_m_step(W, B, V.coo, V.w_s, V.acc_w, V.lane);
-    if (has_next && Wn.has_slice && Wn.m > 0) load8_clamped(B, Wn.b, Wn.m < 8 ? Wn.m : 8);
-    __syncthreads();
-    tile_flush(W.nd, tid, V.acc_w, V.acc);
-    if constexpr (I + 1 < N) {
-        if (has_next) tiled_stage<WEIGHTED, MODE, I + 1, N>(V, in, Tn, Wn, A, B, thv, tidn, ll);
-    }
-}
-
-template <bool WEIGHTED, int MODE, int N>
-__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Tile *__restrict__ tiles, int n_tiles, const uint32_t *__restrict__ fwd,
-                                                                    const uint32_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
-                                                                    const int32_t *__restrict__ far_tid, const int32_t *__restrict__ wgt,
-                                                                    const double *__restrict__ theta, double *__restrict__ acc,
-                                                                    double *__restrict__ ll_out) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double red[kTiledThreads / 64];
-    TileEnv V;
-    V.tiles = tiles; V.n_tiles = n_tiles; V.stride = (int)gridDim.x; V.fwd = fwd; V.bwd = bwd; V.coo = coo; V.far_tid = far_tid; V.wgt = wgt;
-    V.theta = theta; V.acc = acc;
-    V.lane = threadIdx.x & 63;
-    V.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    V.th_w = lds; V.acc_w = lds + kTiledDictPad; V.w_s = lds + 2 * kTiledDictPad + V.wave * kTiledWr;
-    const Tile T = tiles[blockIdx.x];
-    const TileWave W = tile_wave(T, V.wave, V.lane, fwd, bwd);
-    double thv[4]; int tid[4];
-    int4 A[8], B[8];
-    tile_dict_issue(T, W.nd, far_tid, theta, thv, tid);
-    if (W.has_slice) {
-        load8_clamped(A, W.e, W.k < 8 ? W.k : 8);
-        if (W.m > 0) load8_clamped(B, W.b, W.m < 8 ? W.m : 8);
-    }
-    if (V.lane < 8) V.w_s[emsar::kTileSliceRows + V.lane] = 0.0;
-    double ll = 0.0;
-    tiled_stage<WEIGHTED, MODE, 0, N>(V, (int)blockIdx.x, T, W, A, B, thv, tid, ll);
-    if (MODE == MODE_EM_LL) {
-        double t = block_sum<kTiledThreads>(ll, red);
-        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
-    }
-}
-
-// likelihood terms of the folded single-tid rows: sum_t u_t log theta_t
-__global__ __launch_bounds__(256) void k_single_ll(int n, const double *__restrict__ u, const double *__restrict__ theta, double *ll_out) {
-    __shared__ double red[4];
-    double s = 0.0;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
-        double x = theta[t], c = u[t];
-        if (c > 0.0 && x > 0.0) s += c * log(x);
-    }
-    double tot = block_sum<256>(s, red);
-    if (threadIdx.x == 0 && tot != 0.0) atomic_add_f64(ll_out, tot);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_pass_csr: the same pass on the caller's CSR (any row order), one lane per row.
-// ------------------------------------------------------------------------------------------------
-template <typename PTR, bool WEIGHTED, int MODE>
-__global__ __launch_bounds__(256) void k_pass_csr(int64_t n_rows, const PTR *__restrict__ row_ptr,
-                                                  const int32_t *__restrict__ col, const int32_t *__restrict__ wgt,
-                                                  const double *__restrict__ rowval, const double *__restrict__ theta,
-                                                  double *__restrict__ acc, double *__restrict__ ll_out) {
-    __shared__ double red[4];
-    double ll = 0.0;
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) {
-        const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-        double w;
-        if (MODE == MODE_SCATTER) {
-            w = rowval[r];
-        } else {
-            double S = 0.0;
-            for (uint64_t k = b; k < e; k++) S += theta[col[k]];
-            double rw = WEIGHTED ? (double)wgt[r] : 1.0;
-            bool live = (S > 0.0) && (rw > 0.0);
-            w = live ? rw / S : 0.0;
-            if (MODE == MODE_EM_LL && live) ll += rw * log(S);
-        }
-        if (w != 0.0)
-            for (uint64_t k = b; k < e; k++) atomic_add_f64(&acc[col[k]], w);
-    }
-    if (MODE == MODE_EM_LL) {
-        double t = block_sum<256>(ll, red);
-        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// T-sized vector kernels
-// ------------------------------------------------------------------------------------------------
-__global__ void k_fill_start(int n, const double *__restrict__ den, double *__restrict__ theta) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) theta[t] = den[t] > 0.0 ? 1.0 : 0.0;  // uniform interior start; tids outside F are defined 0
-}
-
-// theta_out = theta_in * acc / den ; acc <- 0 ; scal.delta = max |dtheta| / (theta_out + floor)
-// grid-stride, one atomicMax per workgroup (hundreds of same-address atomics cost ~12 ns each)
-__global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
-                                                const double *__restrict__ den, const double *__restrict__ u /* folded single-tid rows, may be null */,
-                                                double *__restrict__ th_out, double abs_floor, double count_floor, double zero_cut, Scal *scal,
-                                                const uint8_t *__restrict__ kind /* non-null: only KIND_STREAMED transcripts enter the stopping rule */,
-                                                int to_delta1 /* the first (plain) step of a SQUAREM cycle: the cycle's stopping rule */) {
-    __shared__ double red[4];
-    double d = 0.0;
-    const double abs_step = scal->abs_step_cur;      // written by k_cycle_begin, nobody writes it during a pass
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
-        double a = acc[t], dn = den[t], x = th_in[t];
-        // a row {t} contributes R/theta_t to acc_t, i.e. R to theta_t*acc_t: added analytically (TILED layout)
-        double y = dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
-        th_out[t] = y;
-        acc[t] = 0.0;
-        double fl = abs_floor;
-        if (count_floor > 0.0 && dn > 0.0) fl = fmax(fl, count_floor / dn);    // floor expressed in inferred reads
-        double dd = fabs(y - x) / (fabs(y) + fl);
-        if (!(dd == dd)) dd = __builtin_huge_val();  // NaN -> +inf so that the host sees it
-        if (y < zero_cut && y <= x) dd = 0.0;        // below the print quantum and still falling: prints as 0.000000 either way
-        if (fabs(y - x) < abs_step) dd = 0.0;         // moves by less than abs_step per pass (emsar_em_params.abs_step)
-        if (kind && kind[t] != emsar::KIND_STREAMED) dd = 0.0;
-        d = fmax(d, dd);
-    }
-    for (int o = 32; o > 0; o >>= 1) d = fmax(d, __shfl_xor(d, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        d = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-        // the word only grows during a kernel: workgroups whose maximum is already covered skip the same-address atomic
-        unsigned long long *dst = to_delta1 ? &scal->delta1_bits : &scal->delta_bits;
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
-        if (d > 0.0 && bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
-    }
-}
-
-// abs_step_base > 0: the projected-drift bound of emsar_em_params.abs_step, |dtheta| < base * 2e5 / K at pass K >= 1000.  K is
-// counted here, on the device, so that a cycle recorded once in a hipGraph carries the right bound at every replay.
-__global__ void k_cycle_begin(Scal *s, double abs_step_base, int passes_in_cycle) {
-    s->ll[0] = s->ll[1] = s->ll[2] = s->ll[3] = 0.0;
-    s->sr2 = s->sv2 = s->pen1 = s->penx = 0.0;
-    s->delta_bits = 0ull; s->delta1_bits = 0ull;
-    const long long done = s->passes;
-    s->abs_step_cur = abs_step_base > 0.0 ? abs_step_base * 2e5 / (double)(done + 1 > 1000 ? done + 1 : 1000) : 0.0;
-    s->passes = done + passes_in_cycle;
-}
-__global__ void k_scal_init(Scal *s) {
-    s->stepmax = 1.0; s->s_used = 1.0; s->accepted = 0; s->rejected = 0; s->sum_a = s->sum_b = 0.0;
-    s->passes = 0; s->abs_step_cur = 0.0;
-}
-
-// ---- the SQUAREM cycle of the streaming solve with the O(T) work folded into the three update kernels ----
-// (8 launches per cycle instead of 13: on a problem of a few thousand rows the cycle is pure launch latency)
-//   k_update_p1   th1 = EM(th0); stopping rule of the cycle -> delta1_bits
-//   k_update_p2   th2 = EM(th1); F(th1) terms: sum u log th1 -> ll[1], sum th1*den -> pen1; |r|^2, |v|^2
-//   k_sq_extrap_ll thx = th0 + 2 s r + s^2 v  (Varadhan & Roland 2008, S3: s = |r|/|v| clamped to [1, stepmax]); components that
-//                 would leave the interior keep the plain EM value th2; s <= 1.01 -> thx = th2; + sum u log thx -> ll[2]
-//   k_update_p3   th0 = accepted ? EM(thx) : th2, accepted iff F(thx) >= F(th1), F = ll - sum theta*den; step bounds x4 / :4
-__device__ __forceinline__ double em_new_theta(double x, double a, double dn, const double *u, int t) {
-    return dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
-}
-__global__ __launch_bounds__(256) void k_update_p2(int n, const double *__restrict__ th0, const double *__restrict__ th1, double *__restrict__ acc,
-                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th2, Scal *scal) {
-    __shared__ double red[4];
-    double r2 = 0, v2 = 0, p1 = 0, l1 = 0;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
-        const double x = th1[t], dn = den[t];
-        const double y = em_new_theta(x, acc[t], dn, u, t);
-        th2[t] = y;
-        acc[t] = 0.0;
-        const double r = x - th0[t], v = (y - x) - r;
-        r2 += r * r; v2 += v * v; p1 += x * dn;
-        if (u) { const double c = u[t]; if (c > 0.0 && x > 0.0) l1 += c * log(x); }
-    }
-    double a = block_sum<256>(r2, red); __syncthreads();
-    double b = block_sum<256>(v2, red); __syncthreads();
-    double c = block_sum<256>(p1, red); __syncthreads();
-    double d = block_sum<256>(l1, red);
-    if (threadIdx.x == 0) {
-        atomic_add_f64(&scal->sr2, a); atomic_add_f64(&scal->sv2, b); atomic_add_f64(&scal->pen1, c);
-        if (d != 0.0) atomic_add_f64(&scal->ll[1], d);
-    }
-}
-__global__ __launch_bounds__(256) void k_sq_extrap_ll(int n, const double *__restrict__ th0, const double *__restrict__ th1,
-                                                      const double *__restrict__ th2, const double *__restrict__ den, const double *__restrict__ u,
-                                                      double *__restrict__ thx, Scal *scal) {
-    __shared__ double red[4];
-    double s = scal->sv2 > 0.0 ? sqrt(scal->sr2 / scal->sv2) : 1.0;
-    s = fmin(fmax(s, 1.0), scal->stepmax);
-    const bool extrap = s > 1.01;
-    double px = 0, lx = 0;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
-        double x2 = th2[t], x = x2;
-        if (extrap) {
-            double r = th1[t] - th0[t], v = (x2 - th1[t]) - r;
-            double y = th0[t] + 2.0 * s * r + s * s * v;
-            x = (y > 0.0 && x2 > 0.0) ? y : x2;
-        }
-        thx[t] = x;
-        px += x * den[t];
-        if (u) { const double c = u[t]; if (c > 0.0 && x > 0.0) lx += c * log(x); }
-    }
-    double p = block_sum<256>(px, red); __syncthreads();
-    double l = block_sum<256>(lx, red);
-    if (threadIdx.x == 0) {
-        atomic_add_f64(&scal->penx, p);
-        if (l != 0.0) atomic_add_f64(&scal->ll[2], l);
-        if (blockIdx.x == 0) scal->s_used = extrap ? s : 1.0;
-    }
-}
-__global__ __launch_bounds__(256) void k_update_p3(int n, const double *__restrict__ thx, const double *__restrict__ th2, double *__restrict__ acc,
-                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th0, Scal *scal) {
-    const double s = scal->s_used;
-    const bool extrap = s > 1.0;
-    const bool ok = !extrap || (scal->ll[2] - scal->penx >= scal->ll[1] - scal->pen1);
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
-        const double y = em_new_theta(thx[t], acc[t], den[t], u, t);
-        acc[t] = 0.0;
-        th0[t] = ok ? y : th2[t];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {      // nobody reads these three during this kernel
-        double sm = scal->stepmax;
-        if (!ok) { scal->rejected++; if (s >= sm) sm = fmax(1.0, sm / 4.0); }
-        else { scal->accepted++; }
-        if ((ok ? s : 1.0) >= sm) sm *= 4.0;
-        scal->stepmax = sm;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_solve_sets: the SET-RESIDENT solver.  One workgroup owns one connected set (sets.hpp) and runs the whole
-// SQUAREM-accelerated EM on it out of LDS: theta vectors, den, the folded single-row counts, the row weights and
-// the 16-bit CSR/CSC indices are loaded once, then every pass is two LDS sweeps (E-step over rows, M-step over
-// transcripts through the CSC -- no atomics, so the result is reproducible bit for bit) and a workgroup
-// reduction.  No global synchronisation, no kernel launch per pass: a pass costs ~1 us instead of the ~30 us
-// launch-latency floor of the streaming kernels, and every set stops at its own convergence.
-// Same update, same start (theta = 1 where den > 0), same stopping rule and the same likelihood-safeguarded S3
-// step as the streaming solve below, so both reach the same fixed point.
-// ------------------------------------------------------------------------------------------------
-struct SetStat { int32_t passes, converged; double delta; };
-struct SetSolveParams { double tol, abs_floor, count_floor, zero_cut, abs_step; int32_t max_iter, accel; };
-
-// Wave-wide reductions on the DPP path (row shifts inside rows of 16 lanes, then row broadcasts; the total lands in lane
-// 63 and is read back as a scalar): ~6 cross-lane moves per value instead of the twelve ds_bpermute round trips of a
-// shuffle butterfly.  The per-set solver is a chain of dependent steps, so the latency of its reductions is pass time.
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v, double identity) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v), id = (unsigned long long)__double_as_longlong(identity);
-    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)id, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(id >> 32), (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
-}
-__device__ __forceinline__ double wave_bcast63(double v) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ double wave_sum_dpp(double v) {
-    v += dpp_move<0x111>(v, 0.0);      // row_shr:1
-    v += dpp_move<0x112>(v, 0.0);      // row_shr:2
-    v += dpp_move<0x114>(v, 0.0);      // row_shr:4
-    v += dpp_move<0x118>(v, 0.0);      // row_shr:8   -> lane 15 of every row holds its row's sum
-    v += dpp_move<0x142>(v, 0.0);      // row_bcast:15 -> lane 31 / 63 hold the sums of rows 0-1 / 2-3 (plus their own rows)
-    v += dpp_move<0x143>(v, 0.0);      // row_bcast:31 -> lane 63 holds the wave's sum
-    return wave_bcast63(v);
-}
-__device__ __forceinline__ double wave_max_dpp(double v) {      // v >= 0
-    v = fmax(v, dpp_move<0x111>(v, 0.0));
-    v = fmax(v, dpp_move<0x112>(v, 0.0));
-    v = fmax(v, dpp_move<0x114>(v, 0.0));
-    v = fmax(v, dpp_move<0x118>(v, 0.0));
-    v = fmax(v, dpp_move<0x142>(v, 0.0));
-    v = fmax(v, dpp_move<0x143>(v, 0.0));
-    return wave_bcast63(v);
-}
-
-template <int THREADS, int N>
-__device__ __forceinline__ void set_reduce_sum(double (&v)[N], double *red) {
-#pragma unroll
-    for (int i = 0; i < N; i++) v[i] = wave_sum_dpp(v[i]);
-    if (THREADS > 64) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        __syncthreads();                       // red may still be read from the previous reduction
-        if (lane == 0)
-#pragma unroll
-            for (int i = 0; i < N; i++) red[wave * N + i] = v[i];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            double t = 0;
-            for (int w = 0; w < THREADS / 64; w++) t += red[w * N + i];
-            v[i] = t;
-        }
-    }
-}
-template <int THREADS>
-__device__ __forceinline__ double set_reduce_max(double v, double *red) {
-    v = wave_max_dpp(v);
-    if (THREADS > 64) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        __syncthreads();
-        if (lane == 0) red[wave] = v;
-        __syncthreads();
-        double t = 0;
-        for (int w = 0; w < THREADS / 64; w++) t = fmax(t, red[w]);
-        v = t;
-    }
-    return v;
-}
-
-// 1/x for normal positive x: v_rcp_f64 (about half the mantissa) refined by two Newton steps -- five dependent
-// instructions instead of the dozen of the IEEE division sequence (scaling, fix-up).  The per-set solver is a chain of
-// dependent steps; theta, den and the row sums it divides by are far from the exponent range where the fix-ups matter.
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
-
-struct SetLds {
-    double *den, *u, *w, *rw, *red;
-    const uint16_t *rp, *ent, *cp, *crow;
-    int nt, nr;
-};
-
-// E-step over the rows at x, then M-step: y = (x*acc + u)/den.  Returns this thread's share of sum R log S (+ the
-// folded single rows' u log x) when LL.
-template <int THREADS, bool LL>
-__device__ __forceinline__ double set_em_estep(const SetLds &L, const double *x) {
-    double ll = 0.0;
-    for (int j = threadIdx.x; j < L.nr; j += THREADS) {
-        double S = 0.0;
-        const int b = L.rp[j], e = L.rp[j + 1];
-        for (int k = b; k < e; k += 4) {  // four independent index -> value chains in flight, also for the last 1..3 entries
-            const int l = e - 1;
-            const int i0 = L.ent[k], i1 = L.ent[k + 1 < e ? k + 1 : l], i2 = L.ent[k + 2 < e ? k + 2 : l], i3 = L.ent[k + 3 < e ? k + 3 : l];
-            const double v0 = x[i0], v1 = x[i1], v2 = x[i2], v3 = x[i3];
-            S += (v0 + (k + 1 < e ? v1 : 0.0)) + ((k + 2 < e ? v2 : 0.0) + (k + 3 < e ? v3 : 0.0));
-        }
-        const double r = L.rw[j];
-        const bool live = S > 0.0;
-        L.w[j] = live ? r * fast_rcp(S) : 0.0;
-        if (LL && live) ll += r * log(S);
-    }
-    __syncthreads();
-    return ll;
-}
-__device__ __forceinline__ double set_em_acc(const SetLds &L, int i) {
-    double a = 0.0;
-    const int b = L.cp[i], e = L.cp[i + 1];
-    for (int k = b; k < e; k += 4) {
-        const int l = e - 1;
-        const int j0 = L.crow[k], j1 = L.crow[k + 1 < e ? k + 1 : l], j2 = L.crow[k + 2 < e ? k + 2 : l], j3 = L.crow[k + 3 < e ? k + 3 : l];
-        const double v0 = L.w[j0], v1 = L.w[j1], v2 = L.w[j2], v3 = L.w[j3];
-        a += (v0 + (k + 1 < e ? v1 : 0.0)) + ((k + 2 < e ? v2 : 0.0) + (k + 3 < e ? v3 : 0.0));
-    }
-    return a;
-}
-__device__ __forceinline__ double set_em_update(double x, double a, double u, double dn) {
-    return dn > 0.0 ? (x > 0.0 ? (x * a + u) * fast_rcp(dn) : 0.0) : 0.0;
-}
-
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__restrict__ desc, const int32_t *__restrict__ g_tid,
-                                                        const double *__restrict__ g_u, const double *__restrict__ row_w,
-                                                        const uint16_t *__restrict__ rp_g, const uint16_t *__restrict__ ent_g,
-                                                        const uint16_t *__restrict__ cp_g, const uint16_t *__restrict__ crow_g,
-                                                        const double *__restrict__ den_g, double *__restrict__ theta_g,
-                                                        SetStat *__restrict__ stat, SetSolveParams P) {
-    extern __shared__ double smem[];
-    const emsar::SetDesc d = desc[blockIdx.x];
-    const int nt = (int)d.n_t, nr = (int)d.n_r, nnz = (int)d.nnz;
-    double *A = smem, *B = A + nt, *Cc = B + nt;
-    SetLds L;
-    L.den = Cc + nt; L.u = L.den + nt; L.w = L.u + nt; L.rw = L.w + nr; L.red = L.rw + nr;
-    uint16_t *rp = (uint16_t *)(L.red + emsar::kSetRedDoubles), *ent = rp + (nr + 1), *cp = ent + nnz, *crow = cp + (nt + 1);
-    L.rp = rp; L.ent = ent; L.cp = cp; L.crow = crow; L.nt = nt; L.nr = nr;
-    for (int i = threadIdx.x; i < nt; i += THREADS) {
-        const double dn = den_g[g_tid[d.tid_off + i]];
-        L.den[i] = dn; L.u[i] = g_u[d.tid_off + i];
-        A[i] = dn > 0.0 ? 1.0 : 0.0;
-    }
-    for (int j = threadIdx.x; j < nr; j += THREADS) L.rw[j] = row_w[d.row_off + j];
-    for (int j = threadIdx.x; j <= nr; j += THREADS) rp[j] = rp_g[d.rp_off + j];
-    for (int i = threadIdx.x; i <= nt; i += THREADS) cp[i] = cp_g[d.cp_off + i];
-    for (int k = threadIdx.x; k < nnz; k += THREADS) { ent[k] = ent_g[d.ent_off + k]; crow[k] = crow_g[d.ent_off + k]; }
-    __syncthreads();
-
-    double stepmax = 1.0, delta = __builtin_huge_val();
-    int passes = 0, converged = 0;
-    double *res = A;
-    for (;;) {
-        // pass 1 (plain): B = EM(A); the stopping rule is measured on this step only
-        (void)set_em_estep<THREADS, false>(L, A);
-        double dloc = 0.0;
-        for (int i = threadIdx.x; i < nt; i += THREADS) {
-            const double x = A[i], dn = L.den[i];
-            const double y = set_em_update(x, set_em_acc(L, i), L.u[i], dn);
-            B[i] = y;
-            double fl = P.abs_floor;
-            if (P.count_floor > 0.0 && dn > 0.0) fl = fmax(fl, P.count_floor / dn);
-            double dd = fabs(y - x) * fast_rcp(fabs(y) + fl);
-            if (!(dd == dd)) dd = __builtin_huge_val();
-            if (y < P.zero_cut && y <= x) dd = 0.0;
-            if (fabs(y - x) * (double)(passes + 1 > 1000 ? passes + 1 : 1000) < P.abs_step * 2e5) dd = 0.0;   // projected drift, see emsar_em_params.abs_step
-            dloc = fmax(dloc, dd);
-        }
-        delta = set_reduce_max<THREADS>(dloc, L.red);
-        __syncthreads();
-        passes++;
-        res = B;
-        if (delta < P.tol) { converged = 1; break; }
-        if (passes >= P.max_iter || delta == __builtin_huge_val()) break;
-        if (!P.accel) { double *t = A; A = B; B = t; continue; }
-        // pass 2: C = EM(B) with F(B); r = B-A, v = (C-B)-r
-        double s4[4];
-        s4[0] = set_em_estep<THREADS, true>(L, B);
-        s4[1] = s4[2] = s4[3] = 0.0;
-        for (int i = threadIdx.x; i < nt; i += THREADS) {
-            const double x = B[i], dn = L.den[i], u = L.u[i];
-            const double y = set_em_update(x, set_em_acc(L, i), u, dn);
-            Cc[i] = y;
-            if (u > 0.0 && x > 0.0) s4[0] += u * log(x);
-            s4[1] += x * dn;
-            const double r = x - A[i], v = (y - x) - r;
-            s4[2] += r * r; s4[3] += v * v;
-        }
-        set_reduce_sum<THREADS, 4>(s4, L.red);
-        const double F1 = s4[0] - s4[1];
-        double s = s4[3] > 0.0 ? sqrt(s4[2] / s4[3]) : 1.0;
-        s = fmin(fmax(s, 1.0), stepmax);
-        const bool extrap = s > 1.01;
-        // extrapolated point, in place of B
-        double s2[2] = {0.0, 0.0};
-        __syncthreads();
-        for (int i = threadIdx.x; i < nt; i += THREADS) {
-            const double x2 = Cc[i];
-            double x = x2;
-            if (extrap) {
-                const double r = B[i] - A[i], v = (x2 - B[i]) - r;
-                const double y = A[i] + 2.0 * s * r + s * s * v;
-                x = (y > 0.0 && x2 > 0.0) ? y : x2;
-            }
-            B[i] = x;
-            s2[1] += x * L.den[i];
-        }
-        __syncthreads();
-        // pass 3: A = EM(B) with F(B)
-        s2[0] = set_em_estep<THREADS, true>(L, B);
-        for (int i = threadIdx.x; i < nt; i += THREADS) {
-            const double x = B[i], u = L.u[i];
-            A[i] = set_em_update(x, set_em_acc(L, i), u, L.den[i]);
-            if (u > 0.0 && x > 0.0) s2[0] += u * log(x);
-        }
-        set_reduce_sum<THREADS, 2>(s2, L.red);
-        const bool ok = !extrap || (s2[0] - s2[1] >= F1);
-        __syncthreads();
-        if (!ok) {
-            for (int i = threadIdx.x; i < nt; i += THREADS) A[i] = Cc[i];
-            if (s >= stepmax) stepmax = fmax(1.0, stepmax / 4.0);
-        }
-        if ((ok ? s : 1.0) >= stepmax) stepmax *= 4.0;
-        __syncthreads();
-        passes += 2;
-        res = A;
-        if (passes >= P.max_iter) break;
-    }
-    for (int i = threadIdx.x; i < nt; i += THREADS) theta_g[g_tid[d.tid_off + i]] = res[i];
-    if (threadIdx.x == 0) { stat[blockIdx.x].passes = passes; stat[blockIdx.x].converged = converged; stat[blockIdx.x].delta = delta; }
-}
-
-// EUMA [rows][nfl] -> [nfl][rows] through a 64 x 64 LDS tile (once per rsh)
-__global__ __launch_bounds__(256) void k_transpose_i32(int64_t n_rows, int nfl, const int32_t *__restrict__ in, int32_t *__restrict__ out) {
-    __shared__ int32_t tile[64][65];
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
-    const int c0 = (int)blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int j = ty; j < 64; j += 4) {
-        const int64_t r = r0 + j; const int c = c0 + tx;
-        tile[j][tx] = (r < n_rows && c < nfl) ? in[(size_t)r * (size_t)nfl + (size_t)c] : 0;
-    }
-    __syncthreads();
-    for (int j = ty; j < 64; j += 4) {
-        const int c = c0 + j; const int64_t r = r0 + tx;
-        if (r < n_rows && c < nfl) out[(size_t)c * (size_t)n_rows + (size_t)r] = tile[tx][j];
-    }
-}
-// compute_adjEUMA (emsar_functions.c:2517-2523): one lane per row, fragment lengths in ascending order, product and sum
-// rounded separately (no FMA) -- bit-identical to the reference's scalar loop; every load is a coalesced 256 B per wave
-__global__ __launch_bounds__(256) void k_adj_euma(int64_t n_rows, int nfl, const int32_t *__restrict__ euma_t, const double *__restrict__ wf,
-                                                  double *__restrict__ out) {
-#pragma clang fp contract(off)   // hipcc fuses a + x*y into an FMA by default (one rounding instead of the reference's two);
-                                 // plain operators: the __dmul_rn / __dadd_rn wrappers carry their own contraction flag
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_rows) return;
-    double a = 0.0;
-    int i = 0;
-    for (; i + 8 <= nfl; i += 8) {
-        int32_t e[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) e[j] = euma_t[(size_t)(i + j) * (size_t)n_rows + (size_t)r];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { const double p = wf[i + j] * (double)e[j]; a = a + p; }
-    }
-    for (; i < nfl; i++) { const double p = wf[i] * (double)euma_t[(size_t)i * (size_t)n_rows + (size_t)r]; a = a + p; }
-    out[r] = a;
-}
-
-// transcripts outside every multi-transcript set: theta = (reads of its single-transcript rows) / den
-__global__ void k_closed_form(int n, const uint8_t *__restrict__ kind, const double *__restrict__ usum,
-                              const double *__restrict__ den, double *__restrict__ theta) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n && kind[t] == emsar::KIND_CLOSED) theta[t] = den[t] > 0.0 ? usum[t] / den[t] : 0.0;
-}
-
-// sum of the mean FPKM (the TPM denominator, emsar_functions.c:3176-3181): ONE workgroup, fixed order -- the printed TPM
-// column must not depend on the arrival order of atomics (the per-set solver is bit-reproducible, its output should be too)
-__global__ __launch_bounds__(1024) void k_sum(int n, const double *__restrict__ x, double *out) {
-    __shared__ double red[16];
-    double s = 0.0;
-    for (int t = threadIdx.x; t < n; t += 1024) s += x[t];
-    double tot = block_sum<1024>(s, red);
-    if (threadIdx.x == 0) *out = *out + tot;
-}
-__global__ __launch_bounds__(256) void k_dot(int n, const double *__restrict__ x, const double *__restrict__ y, double *out) {
-    __shared__ double red[4];
-    int t = blockIdx.x * 256 + threadIdx.x;
-    double s = block_sum<256>(t < n ? x[t] * y[t] : 0.0, red);
-    if (threadIdx.x == 0) atomic_add_f64(out, s);
-}
-// print_FPKMfinal arithmetic (emsar_functions.c:3203-3207): TPM, iReadcount, Round_off
-__global__ void k_normalise(int n, const double *__restrict__ mean, const double *__restrict__ ieuma, double nreads_m,
-                            const double *total, double *__restrict__ tpm, double *__restrict__ ir, int32_t *__restrict__ iri) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    double m = mean[t];
-    tpm[t] = m * 1E6 / *total;
-    double x = (ieuma[t] / 1E3) * m * nreads_m;
-    ir[t] = x;
-    int xi = (int)x;
-    iri[t] = (x - xi >= 0.5) ? xi + 1 : xi;
-}
-
-}  // namespace
+#include "kernels_common.hpp"
+#include "kernels_windowed.hpp"
+#include "kernels_tiled.hpp"
+#include "kernels_vector.hpp"
+#include "kernels_sets.hpp"
 
 // ==================================================================================================
 // context

@@ -1,0 +1,55 @@
+// kernels_common.hpp -- device scalars of a solve, FP64 atomics, wave / workgroup reductions, pass modes
+#pragma once
+// included by emsar_hip.hip only (one translation unit: the kernels live in its anonymous namespace)
+
+namespace {
+
+using emsar::Chunk;
+using emsar::Tile;
+constexpr int kPassThreads = 512;     // 8 waves per workgroup
+constexpr int kDefaultWindow = 4096;  // 2 x 32 KiB of LDS per workgroup -> 2 workgroups per CU
+constexpr int64_t kChunkEntries = 65536;
+
+// ------------------------------------------------------------------------------------------------
+// device scalars of one solve (lives in HBM, polled by the host every check_every cycles)
+// ------------------------------------------------------------------------------------------------
+struct Scal {
+    double ll[4];                 // sum_c R_c log S_c at the input of pass 0/1/2 of the cycle; [3] scratch
+    double sr2, sv2, pen1, penx;  // SQUAREM norms, sum theta*den of th1 and of the extrapolated point
+    double stepmax, s_used;
+    unsigned long long delta_bits;  // max_t |dtheta|/(theta+floor) as IEEE bits (non-negative -> integer max)
+    unsigned long long delta1_bits; // the same, frozen after the first (plain) pass of a SQUAREM cycle
+    int32_t accepted, rejected;
+    double sum_a, sum_b;          // generic reductions (normalise)
+    long long passes;             // EM passes enqueued before the current cycle (k_cycle_begin keeps it: the cycle may replay from a hipGraph)
+    double abs_step_cur;          // emsar_em_params.abs_step scaled to the pass count of the current cycle (0 = rule off)
+};
+
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) {
+    // gfx950: global_atomic_add_f64 / ds_add_f64 (no CAS loop; compiled with -munsafe-fp-atomics)
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lds_add_f64(double *p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int THREADS>
+__device__ __forceinline__ double block_sum(double v, double *red /* THREADS/64 doubles of LDS */) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < THREADS / 64; i++) t += red[i];
+    return t;  // valid in thread 0
+}
+
+enum PassMode { MODE_EM = 0, MODE_EM_LL = 1, MODE_SCATTER = 2 };
+
+}  // namespace
