@@ -62,4 +62,16 @@ with tempfile.TemporaryDirectory() as d:
     bad = quiet & (np.abs(h - a) > tol(a))
     print("off the reference's own noise mask (%d transcripts): %d differ; max rel diff on FPKM > 1: %.2e"
           % (int(quiet.sum()), int(bad.sum()), float((np.abs(h - a) / np.maximum(a, 1e-300))[quiet & (a > 1)].max())))
+    # the command line stops on the .fpkm print quantum (--zero-cut 2.5e-7 --abs-step 1e-13); the same input at the strict rule
+    t0 = time.time()
+    subprocess.run([HIP, "-q", "--zero-cut", "0", "--abs-step", "0", "--stats-json", os.path.join(d, "st2.json"), "-I", rsh, os.path.join(d, "hs"), "o", aln],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    t_strict = time.time() - t0
+    hs = O.read_fpkm(os.path.join(d, "hs", "o.0.fpkm"))["fpkm"]
+    st2 = json.load(open(os.path.join(d, "st2.json")))["per_sample"][0]
+    print("emsar-hip, strict stopping rule: %.2f s wall, solve %.3f s (%d passes); vs reference off the noise mask: %d differ, max rel diff on FPKM > 1: %.2e"
+          % (t_strict, st2["solve_ms"] / 1e3, st2["em_passes"], int((quiet & (np.abs(hs - a) > tol(a))).sum()),
+             float((np.abs(hs - a) / np.maximum(a, 1e-300))[quiet & (a > 1)].max())))
+    print("emsar-hip print-quantum rules vs strict: %d transcripts differ beyond 1e-5 rel + 1.5e-6, largest |dFPKM| %.3e, largest rel diff on FPKM > 1: %.2e"
+          % (int((np.abs(h - hs) > tol(hs)).sum()), float(np.abs(h - hs).max()), float((np.abs(h - hs) / np.maximum(hs, 1e-300))[hs > 1].max())))
     seg = lambda p: O.read_segments(p, n_tx) if os.path.exists(p) else None
