@@ -54,15 +54,36 @@ typedef struct {
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
-static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i) {
+/* The alignments of a sample are counted on a thread of their own: the first sample of a worker while its GPU context, the
+ * device layout and the EUMA table are being set up, every later one while the sample before it is being solved. */
+typedef struct { worker_arg *w; int i; emsar_counts *cnt; int rc; char err[512]; double secs; pthread_t th; int started; } parse_job;
+static void *parse_main(void *a) {
+    parse_job *j = (parse_job *)a;
+    double t0 = now_s();
+    j->rc = emsar_count_alignments(j->w->rsh, j->w->cfg->aln[j->i], &j->w->cfg->ao, &j->cnt, j->err, sizeof j->err);
+    j->secs = now_s() - t0;
+    return NULL;
+}
+static void parse_start(parse_job *j, worker_arg *w, int i) {
+    memset(j, 0, sizeof *j);
+    j->w = w; j->i = i;
+    if (pthread_create(&j->th, NULL, parse_main, j) == 0) j->started = 1;
+}
+static void parse_wait(parse_job *j) {
+    if (j->started) { pthread_join(j->th, NULL); j->started = 0; }
+    else if (j->w) parse_main(j);                                    /* no thread to be had: count here */
+    j->w = NULL;
+}
+
+static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i, parse_job *parsed) {
     config *cfg = w->cfg; const emsar_rsh *r = w->rsh;
     char err[512] = "", path[4096];
-    emsar_counts *cnt = NULL; emsar_model *m = NULL;
+    emsar_counts *cnt = parsed->cnt; emsar_model *m = NULL;
     double *theta = NULL, *rounds = NULL, *mean = NULL, *sd = NULL, *ieuma = NULL, *tpm = NULL, *ir = NULL, *den = NULL; int32_t *iri = NULL;
-    int rc;
-    double t0 = now_s();
-    rc = emsar_count_alignments(r, cfg->aln[i], &cfg->ao, &cnt, err, sizeof err);
-    w->parse_s[i] = now_s() - t0;
+    int rc = parsed->rc;
+    parsed->cnt = NULL;
+    snprintf(err, sizeof err, "%s", parsed->err);
+    w->parse_s[i] = parsed->secs;
     /* compute_adjEUMA (emsar_main.c:403): L = EUMA . Wf on the device, bit-identical to the host loop */
     double *Ldev = NULL;
     if (rc == 0) {
@@ -140,12 +161,20 @@ done:
 static void *worker_main(void *a) {
     worker_arg *w = (worker_arg *)a;
     emsar_hip_ctx *ctx = NULL;
+    parse_job slot[2];                                               /* the sample in hand and the one being counted ahead */
+    int c = 0;
+    memset(slot, 0, sizeof slot);
+    if (w->worker < w->cfg->n_aln) parse_start(&slot[c], w, w->worker);
     int rc = emsar_hip_create(&ctx, w->device);
     if (rc == 0) rc = emsar_hip_upload_structure(ctx, w->rsh->n_rows, w->rsh->n_tx, w->rsh->row_ptr, w->rsh->col_idx, EMSAR_LAYOUT_AUTO);
     if (rc == 0) rc = emsar_hip_upload_euma(ctx, w->rsh->euma, w->rsh->nfl);     /* once per rsh: compute_adjEUMA runs on the device */
     if (rc) fprintf(stderr, "GPU %d: %s\n", w->device, emsar_hip_strerror(rc));
     for (int i = w->worker; i < w->cfg->n_aln; i += w->n_workers) {
+        parse_job *cur = &slot[c];
+        parse_wait(cur);
+        if (i + w->n_workers < w->cfg->n_aln) parse_start(&slot[c ^ 1], w, i + w->n_workers);
         if (rc) {   /* keep the ordered hand-over alive so the other workers are not stuck */
+            emsar_counts_free(cur->cnt); cur->cnt = NULL;
             pthread_mutex_lock(w->mu);
             while (*w->next_model != i) pthread_cond_wait(w->cv, w->mu);
             (*w->next_model)++;
@@ -153,8 +182,9 @@ static void *worker_main(void *a) {
             pthread_mutex_unlock(w->mu);
             w->status[i] = rc;
         } else {
-            w->status[i] = run_sample(w, ctx, i);
+            w->status[i] = run_sample(w, ctx, i, cur);
         }
+        c ^= 1;
     }
     emsar_hip_destroy(ctx);
     return NULL;
