@@ -27,6 +27,8 @@
 
 #include "../../include/emsar_hip.h"
 #include "internal.hpp"
+#include <cstdlib>
+
 #include "layout.hpp"
 
 namespace {
@@ -39,11 +41,12 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finalise
 }
 
 __global__ __launch_bounds__(256) void k_row_hash(int64_t n_rows, const uint64_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                  uint64_t *__restrict__ h1, uint64_t *__restrict__ h2) {
+                                                  uint64_t *__restrict__ h1, uint64_t *__restrict__ h2, int weak) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_rows) return;
     const uint64_t b = rp[r], e = rp[r + 1];
     uint64_t a = 0x9e3779b97f4a7c15ull * (e - b + 1), c = 0;
+    if (weak) { h1[r] = a; h2[r] = 1ull; return; }   // test hook: every row of one length collides in both hashes and in the tag
     for (uint64_t k = b; k < e; k++) {
         const uint64_t m = mix64((uint64_t)(uint32_t)ci[k] + 0x632be59bd9b4e019ull);
         a += m;                      // sums of per-element mixes: invariant under permutation, sensitive to multiplicity
@@ -193,7 +196,9 @@ extern "C" int emsar_hip_collapse_rows(emsar_hip_ctx *ctx, int64_t n_rows, int32
     CCHK(hipEventCreate(&ev.a)); CCHK(hipEventCreate(&ev.b));
     CCHK(hipEventRecord(ev.a, st));
     const dim3 grid((unsigned)((n_rows + 255) / 256)), block(256);
-    hipLaunchKernelGGL(k_row_hash, grid, block, 0, st, n_rows, d_rp.as<uint64_t>(), d_ci.as<int32_t>(), d_h1.as<uint64_t>(), d_h2.as<uint64_t>());
+    const char *weak_env = getenv("EMSAR_HIP_COLLAPSE_WEAK_HASH");      // tests: force full hash collisions (small inputs only: probing becomes O(distinct rows))
+    const int weak_hash = weak_env && atoi(weak_env) != 0;
+    hipLaunchKernelGGL(k_row_hash, grid, block, 0, st, n_rows, d_rp.as<uint64_t>(), d_ci.as<int32_t>(), d_h1.as<uint64_t>(), d_h2.as<uint64_t>(), weak_hash);
     hipLaunchKernelGGL(k_row_insert, grid, block, 0, st, n_rows, d_rp.as<uint64_t>(), d_ci.as<int32_t>(), row_weight ? d_w.as<int32_t>() : nullptr,
                        d_h1.as<uint64_t>(), d_h2.as<uint64_t>(), d_tab.as<unsigned long long>(), M - 1, d_slot.as<int32_t>(), d_first.as<int32_t>(),
                        d_cnt.as<unsigned long long>());

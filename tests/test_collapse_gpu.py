@@ -87,3 +87,16 @@ def test_edge_cases_and_errors(dev):
         dev.collapse_rows(100, rp, np.concatenate(rows).astype(np.int32), np.array([-1, 5, 0], dtype=np.int32))
     with pytest.raises(EmsarHipError):
         dev.collapse_rows(50, rp, np.concatenate(rows).astype(np.int32))       # tid out of range
+
+
+def test_full_hash_collisions_are_resolved_by_comparison(monkeypatch):
+    """Test hook EMSAR_HIP_COLLAPSE_WEAK_HASH: every row of one length gets the same two hashes and the same table tag, so
+    each insert walks a probe chain of unrelated rows and must tell them apart by comparing the id multisets."""
+    monkeypatch.setenv("EMSAR_HIP_COLLAPSE_WEAK_HASH", "1")
+    s = synth.make_matrix(n_tx=300, n_reads=6000, law="human", xfam=0.05, seed=11)
+    with EmsarHip(0) as ctx:
+        got = ctx.collapse_rows(s["n_tx"], s["row_ptr"], s["col_idx"])
+    want = O.collapse_rows(s["row_ptr"], s["col_idx"])
+    for a, b in zip((got[0], got[1], got[2].astype(np.int64), got[3]), want):
+        np.testing.assert_array_equal(a, b)
+    assert len(got[2]) > 200                                       # many distinct multisets of equal length shared one chain
