@@ -502,14 +502,15 @@ static void counts_add(emsar_counts *c, const emsar_counts *q) {
     c->reads_bad_fraglen += q->reads_bad_fraglen; c->reads_discrepant += q->reads_discrepant; c->reads_no_segment += q->reads_no_segment;
 }
 
-/* ---- single-end BAM counted by a pool of threads ------------------------------------------------------------------------
+/* ---- BAM counted by a pool of threads ------------------------------------------------------------------------
  * A BAM record carries its length but no sync mark, so a worker cannot start in the middle of the inflated stream.  The
  * calling thread therefore walks the stream (inflated ahead of it by pbgzf's own pool), hops from record to record and
  * cuts it into batches of whole records.  It reads just enough of each record -- refID, FLAG and the read name, all in
  * the fixed part -- to cut only where a KEPT record opens a new read group (kept = aligned and on the wanted strand:
  * the same test count_range applies, emsar_functions.c:359,748), so the batches are independent: each worker runs the
  * sequential loop on its batches and adds into its own counts, and the sums equal the one-thread result exactly.
- * Paired-end BAM stays on one thread (mates may come in either order, so a cut cannot tell where a pair begins). */
+ * Paired-end: the unit is the pair the sequential loop would form (an unaligned record is skipped singly, an aligned one
+ * is read together with its successor), kept by the same orientation test (emsar_functions.c:514-548). */
 typedef struct bam_batch { unsigned char *buf; size_t n, cap; int64_t index; struct bam_batch *next; } bam_batch;
 typedef struct {
     pthread_mutex_t mu; pthread_cond_t cv_work, cv_free;
@@ -567,7 +568,7 @@ static void bam_batch_put(bam_pool *P, bam_batch *b) {
 static int count_bam_parallel(const emsar_rsh *r, const char *path, const emsar_aln_opts *o, emsar_counts **out,
                               char *err, size_t errlen) {
     const int nt = host_threads();
-    if (o->format != 2 || o->pe || nt <= 1 || !path || !path[0] || strcmp(path, "-") == 0) return -100;
+    if (o->format != 2 || nt <= 1 || !path || !path[0] || strcmp(path, "-") == 0) return -100;
     size_t batch_bytes = (size_t)8 << 20;
     const char *e = getenv("EMSAR_HOST_RANGE_BYTES");                 /* tests: many batches on small files */
     if (e && atoll(e) > 0) batch_bytes = (size_t)atoll(e);
@@ -607,6 +608,10 @@ static int count_bam_parallel(const emsar_rsh *r, const char *path, const emsar_
     if (rc == EMSAR_HOST_OK) {
         bam_batch *cur = bam_batch_get(&P);
         unsigned char prev[256]; size_t prev_n = 0; int have_prev = 0;
+        /* paired-end: the worker skips an unaligned record singly and reads an aligned one together with the record after
+         * it (emsar_functions.c:514-520), so the pairs are known from refID alone; the first mate is held until the second
+         * has shown whether the pair is kept */
+        int have_r1 = 0; size_t r1_off = 0; int r1_flag = 0, r1_pos = 0, r1_ok = 0;
         for (;;) {
             unsigned char h[4];
             long got = bam_get(bam, h, 4);
@@ -623,34 +628,55 @@ static int count_bam_parallel(const emsar_rsh *r, const char *path, const emsar_
             memcpy(rec, h, 4);
             if (bam_rd(bam, rec + 4, (size_t)bs)) { malformed = 1; break; }
             const unsigned char *q = rec + 4;
-            const int32_t refid = le32(q);
+            const int32_t refid = le32(q), pos = le32(q + 4);
             const int l_name = q[8], flag = q[14] | (q[15] << 8);
-            const char strand = (flag & 0x10) ? '-' : '+';
-            const int kept = refid >= 0 && refid < bam->n_ref && 32 + (size_t)l_name <= (size_t)bs && l_name >= 1 &&
-                             !(o->strand != 0 && o->strand != strand);
+            const int aligned = refid >= 0 && refid < bam->n_ref;
+            const int name_ok = 32 + (size_t)l_name <= (size_t)bs && l_name >= 1;
+            size_t unit = cur->n;                                     /* where the record (or its pair) begins in the batch */
+            cur->n += 4 + (size_t)bs;
+            int kept;
+            if (!o->pe) {
+                const char strand = (flag & 0x10) ? '-' : '+';
+                kept = aligned && name_ok && !(o->strand != 0 && o->strand != strand);
+            } else if (!have_r1) {
+                if (aligned) { have_r1 = 1; r1_off = unit; r1_flag = flag; r1_pos = pos; r1_ok = name_ok; }
+                continue;
+            } else {                                                  /* this record is the second mate of the pair at r1_off */
+                have_r1 = 0;
+                unit = r1_off;
+                int p1, p2; char s1, s2; int grouped = 1;
+                if ((r1_flag & 0x40) && (flag & 0x80)) { p1 = r1_pos; p2 = pos; s1 = (r1_flag & 0x10) ? '-' : '+'; s2 = (flag & 0x10) ? '-' : '+'; }
+                else if ((flag & 0x40) && (r1_flag & 0x80)) { p1 = pos; p2 = r1_pos; s1 = (flag & 0x10) ? '-' : '+'; s2 = (r1_flag & 0x10) ? '-' : '+'; }
+                else { grouped = 0; p1 = p2 = 0; s1 = s2 = '+'; }        /* the worker stops here: "mates are not grouped" */
+                if (p2 > p1) kept = !(o->strand == '-') && (s1 == '+' && s2 == '-');
+                else kept = !(o->strand == '+') && (s1 == '-' && s2 == '+');
+                kept = kept && grouped && r1_ok;
+            }
             if (kept) {
-                const size_t nl = strnlen((const char *)(q + 32), (size_t)l_name);
-                const int new_group = !have_prev || nl != prev_n || memcmp(prev, q + 32, nl) != 0;
-                if (new_group && cur->n >= batch_bytes) {             /* this record opens the next batch */
+                const unsigned char *nm = cur->buf + unit + 4 + 32;     /* read name of the record, or of the first mate */
+                const size_t nl = strnlen((const char *)nm, (size_t)cur->buf[unit + 4 + 8]);
+                const int new_group = !have_prev || nl != prev_n || memcmp(prev, nm, nl) != 0;
+                memcpy(prev, nm, nl); prev_n = nl; have_prev = 1;
+                if (new_group && unit >= batch_bytes) {               /* this record (pair) opens the next batch */
+                    const size_t moved = cur->n - unit;
                     bam_batch *nb = bam_batch_get(&P);
-                    if (4 + (size_t)bs > nb->cap) {
-                        unsigned char *g = (unsigned char *)realloc(nb->buf, 4 + (size_t)bs + (1 << 16));
+                    if (moved > nb->cap) {
+                        unsigned char *g = (unsigned char *)realloc(nb->buf, moved + (1 << 16));
                         if (!g) { bam_batch_put(&P, nb); rc = EMSAR_HOST_ERR_OOM; break; }
-                        nb->buf = g; nb->cap = 4 + (size_t)bs + (1 << 16);
+                        nb->buf = g; nb->cap = moved + (1 << 16);
                     }
-                    memcpy(nb->buf, rec, 4 + (size_t)bs);
-                    nb->n = 0;
+                    memcpy(nb->buf, cur->buf + unit, moved);
+                    nb->n = moved;
+                    cur->n = unit;
                     cur->index = n_batches++;
                     bam_batch_put(&P, cur);
-                    cur = nb; rec = cur->buf; q = rec + 4;
+                    cur = nb;
                     pthread_mutex_lock(&P.mu);
                     const int failed = P.rc != EMSAR_HOST_OK;
                     pthread_mutex_unlock(&P.mu);
                     if (failed) { cur->n = 0; break; }                /* a batch already failed: whatever follows cannot come first */
                 }
-                memcpy(prev, q + 32, nl); prev_n = nl; have_prev = 1;
             }
-            cur->n += 4 + (size_t)bs;
         }
         cur->index = n_batches++;
         bam_batch_put(&P, cur);                                       /* the last batch (possibly empty) */
@@ -667,11 +693,19 @@ static int count_bam_parallel(const emsar_rsh *r, const char *path, const emsar_
     if (rc == EMSAR_HOST_OK && malformed) { rc = EMSAR_HOST_ERR_FORMAT; if (err) snprintf(err, errlen, "malformed BAM record"); }
     if (rc == EMSAR_HOST_ERR_OOM && err) snprintf(err, errlen, "out of memory");
     if (rc == EMSAR_HOST_OK) {
-        for (int t = 0; t < nt; t++) {
+        for (int t = 0; t < nt && rc == EMSAR_HOST_OK; t++) {
             got |= w[t].got;
-            if (!c) { c = w[t].c; w[t].c = NULL; } else counts_add(c, w[t].c);
+            if (!c) { c = w[t].c; w[t].c = NULL; continue; }
+            counts_add(c, w[t].c);
+            if (w[t].c->readlength != r->hdr_readlength) {            /* learnt from the data (paired-end, header says -1) */
+                if (c->readlength == r->hdr_readlength) c->readlength = w[t].c->readlength;
+                else if (c->readlength != w[t].c->readlength) {
+                    rc = EMSAR_HOST_ERR_FORMAT;
+                    if (err) snprintf(err, errlen, "paired-end data with variable read length is not supported");
+                }
+            }
         }
-        if (!got) {
+        if (rc == EMSAR_HOST_OK && !got) {
             rc = EMSAR_HOST_ERR_FORMAT;
             if (err) snprintf(err, errlen, "no usable alignment in %s (the reference stops with 'NULL alignment list')", path);
         }

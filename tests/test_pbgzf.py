@@ -75,8 +75,8 @@ def test_bam_records_counted_in_parallel_batches(bam_case, threads, batch, monke
 
 @pytest.mark.parametrize("case", ["toy5_bam", "toy5_pe_bam"])
 def test_golden_bam_fixtures_in_parallel_batches(case, monkeypatch, capfd):
-    """The reference's own BAM inputs (both strands, unaligned records between the kept ones): one group per batch gives
-    the one-thread counts; the paired-end file is left to the one-thread loop."""
+    """The reference's own BAM inputs (both strands, unaligned records between the kept ones; mates in either order in the
+    paired-end file): one read group per batch gives the one-thread counts."""
     _build.build_host()
     fx = get_fixture(case)
     r = HL.HostRsh(os.path.join(fx.dir, "index.rsh"))
@@ -94,8 +94,66 @@ def test_golden_bam_fixtures_in_parallel_batches(case, monkeypatch, capfd):
                 res.append((c.R.tobytes(), c.frag_counts.tobytes(), c.total_reads, c.stats))
             except HL.HostError as e:
                 res.append(str(e))
-            assert ("BAM, " in capfd.readouterr().err) == (threads != "1" and not pe)
+            assert ("BAM, " in capfd.readouterr().err) == (threads != "1")
         assert res[0] == res[1] == res[2]
+
+
+def test_paired_end_bam_seams(tmp_path, monkeypatch):
+    """Paired-end BAM built to hit the seams of the batch cutter: read groups of several pairs, pairs that fail the
+    orientation filter inside and between groups (they must not split a group), unaligned records sprinkled singly
+    between pairs (the reader skips them one by one, which shifts the pairing), mates in either order."""
+    import random
+    _build.build_host()
+    fx = get_fixture("toy5_pe")
+    r = HL.HostRsh(os.path.join(fx.dir, "index.rsh"))
+    names = r.names
+    rng = random.Random(9)
+    L = 50
+    lines = ["@SQ\tSN:%s\tLN:100000\n" % n for n in names]
+    rid = 0
+    last_kept = None
+    for _ in range(1500):
+        rid += 1
+        name = "q%d" % (rid if rng.random() > 0.15 or last_kept is None else last_kept)   # now and then the previous id again
+        for _k in range(rng.choice([1, 1, 2, 3, 6])):
+            t = rng.choice(names)
+            a = rng.randrange(0, 300)
+            b = a + rng.randrange(98, 113)                         # fragment 148-162 against the index range 150-160
+            kind = rng.random()
+            if kind < 0.7:      f1, f2 = 0x1 | 0x2 | 0x20 | 0x40, 0x1 | 0x2 | 0x10 | 0x80      # mate 1 forward, mate 2 reverse: kept (ns)
+            elif kind < 0.85:   f1, f2 = 0x1 | 0x2 | 0x10 | 0x40, 0x1 | 0x2 | 0x20 | 0x80      # reversed orientation at these positions: filtered
+            else:               f1, f2 = 0x1 | 0x2 | 0x10 | 0x20 | 0x40, 0x1 | 0x2 | 0x10 | 0x80  # both reverse: filtered
+            m1 = G.sam_line(name, f1, t, a, L, str(L), "=")
+            m2 = G.sam_line(name, f2, t, b, L, str(L), "=")
+            pair = [m1, m2] if rng.random() < 0.6 else [m2, m1]
+            lines += pair
+            if rng.random() < 0.2:
+                lines.append("u%d\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (rid, "A" * L, "I" * L))
+        last_kept = rid
+    sam = str(tmp_path / "pe.sam")
+    open(sam, "w").write("".join(lines))
+    bam = str(tmp_path / "pe.bam")
+    G.sam_to_bam(sam, bam)
+
+    def outcome(threads, batch, strand):
+        monkeypatch.setenv("EMSAR_HOST_THREADS", threads)
+        monkeypatch.setenv("EMSAR_HOST_RANGE_BYTES", batch)
+        try:
+            c = r.count(bam, pe=1, strand=strand, fmt=2)
+        except HL.HostError as e:
+            return str(e)
+        return (c.R.tobytes(), c.frag_counts.tobytes(), c.total_reads, c.stats)      # stats carries readlength
+
+    for strand in ("ns", "ssfr", "ssrf"):
+        want = outcome("1", "1", strand)
+        assert not isinstance(want, str) or "no usable" in want
+        for threads, batch in (("2", "1"), ("5", "700"), ("16", "20000")):
+            assert outcome(threads, batch, strand) == want, (strand, threads, batch)
+    assert not isinstance(outcome("1", "1", "ns"), str)
+    # the same records as SAM text go through the one-thread reader: same counts
+    monkeypatch.setenv("EMSAR_HOST_THREADS", "1")
+    c_sam = r.count(sam, pe=1, strand="ns", fmt=1)
+    assert outcome("4", "1", "ns")[:3] == (c_sam.R.tobytes(), c_sam.frag_counts.tobytes(), c_sam.total_reads)
 
 
 def test_parallel_bam_errors_match_the_one_thread_loop(bam_case, monkeypatch):
