@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -53,6 +54,17 @@ inline void pack10(uint32_t *q, int i, uint32_t id) { q[i / 3] |= (id & 0x3FFu) 
 inline uint32_t unpack10(const uint32_t *q, int i) { return (q[i / 3] >> (10 * (i % 3))) & 0x3FFu; }
 constexpr int kDenseMin = 4;           // columns with fewer entries in a slice use the COO list
 constexpr int64_t kTileEntries = 65536;
+
+// vectors whose resize(n) leaves the new elements uninitialised (resize(n, v) still fills): the big index arrays are
+// sized once and filled by several threads, a zero fill by one thread first would cost as much as the copy
+template <class T> struct no_init_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = no_init_alloc<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+using u32_vec = std::vector<uint32_t, no_init_alloc<uint32_t>>;
+using i64_vec = std::vector<int64_t, no_init_alloc<int64_t>>;
 
 struct Tile {                // 64 bytes
     uint64_t fwd_off;        // byte offset into fwd (multiple of 1024)
@@ -78,11 +90,11 @@ struct TiledLayout {
     std::vector<int32_t> single_tid;
     // tiles
     std::vector<Tile> tiles;
-    std::vector<int64_t> slot_row;      // row slot -> original row, or merged-row id when `merged` (-1 = padding)
+    i64_vec slot_row;                   // row slot -> original row, or merged-row id when `merged` (-1 = padding)
     bool merged = false;                // identical rows were merged: a slot stands for mem_row[mem_ptr[id] .. mem_ptr[id+1])
     std::vector<uint64_t> mem_ptr;
     std::vector<uint32_t> mem_row;
-    std::vector<uint32_t> fwd, bwd;     // packed 10-bit ids
+    u32_vec fwd, bwd;                   // packed 10-bit ids
     std::vector<uint32_t> coo;          // (col_id << 16) | row_id
     std::vector<int32_t> far_tid;
     // leftover rows (too long for a tile): plain CSR + original row ids
@@ -433,7 +445,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 uint32_t empty[4] = {0, 0, 0, 0};                          // unused segment: zero column, padding rows
                 pack10(empty, 0, zero_id);
                 for (int j = 1; j < 12; j++) pack10(empty, j, pad_row);
-                out.bwd.resize(base + (size_t)m * 64 * 4);
+                out.bwd.resize(base + (size_t)m * 64 * 4, 0u);
                 for (int64_t g = 0; g < (int64_t)m * 64; g++) {
                     // logical segment g -> lane g / m, unit g % m ; physical int4 index (unit*64 + lane)
                     int64_t lane = g / m, unit = g % m;
@@ -473,28 +485,51 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         for (int64_t g = 0; g < n_frag; g++) if (frc[(size_t)g] != 0) return frc[(size_t)g];
         const auto tp3 = t_now();
         if (dbg_t) fprintf(stderr, "build_tiled: classify %.0f ms, sort %.0f ms, tiles %.0f ms on %d thread(s)\n", t_ms(tp0, tp1), t_ms(tp1, tp2), t_ms(tp2, tp3), nthr);
+        // concatenate: descriptors, COO pairs and far lists here (small), the three big arrays by the pool, each fragment
+        // into its own range of the final arrays
+        std::vector<size_t> slot_b((size_t)n_frag + 1, 0), fwd_b((size_t)n_frag + 1, 0), bwd_b((size_t)n_frag + 1, 0);
         {
-            size_t nt_ = 0, ns_ = 0, nf_ = 0, nb_ = 0, nc_ = 0, nfar_ = 0;
-            for (const TiledLayout &F : frag) { nt_ += F.tiles.size(); ns_ += F.slot_row.size(); nf_ += F.fwd.size(); nb_ += F.bwd.size(); nc_ += F.coo.size(); nfar_ += F.far_tid.size(); }
-            out.tiles.reserve(nt_); out.slot_row.reserve(ns_); out.fwd.reserve(nf_); out.bwd.reserve(nb_); out.coo.reserve(nc_); out.far_tid.reserve(nfar_);
+            size_t nt_ = 0, nc_ = 0, nfar_ = 0;
+            for (int64_t g = 0; g < n_frag; g++) {
+                const TiledLayout &F = frag[(size_t)g];
+                nt_ += F.tiles.size(); nc_ += F.coo.size(); nfar_ += F.far_tid.size();
+                slot_b[(size_t)g + 1] = slot_b[(size_t)g] + F.slot_row.size();
+                fwd_b[(size_t)g + 1] = fwd_b[(size_t)g] + F.fwd.size();
+                bwd_b[(size_t)g + 1] = bwd_b[(size_t)g] + F.bwd.size();
+            }
+            if (slot_b[(size_t)n_frag] >= ((size_t)1 << 32)) return -1;
+            out.tiles.reserve(nt_); out.coo.reserve(nc_); out.far_tid.reserve(nfar_);
+            out.slot_row.resize(slot_b[(size_t)n_frag]); out.fwd.resize(fwd_b[(size_t)n_frag]); out.bwd.resize(bwd_b[(size_t)n_frag]);
         }
         for (int64_t g = 0; g < n_frag; g++) {
             TiledLayout &F = frag[(size_t)g];
-            const uint64_t fwd_b = (uint64_t)out.fwd.size() * 4, bwd_b = (uint64_t)out.bwd.size() * 4;
-            const uint32_t slot_b = (uint32_t)out.slot_row.size(), far_b = (uint32_t)out.far_tid.size(), coo_b = (uint32_t)out.coo.size();
+            const uint32_t far_b = (uint32_t)out.far_tid.size(), coo_b = (uint32_t)out.coo.size();
             for (Tile t : F.tiles) {
-                t.fwd_off += fwd_b; t.bwd_off += bwd_b; t.row_base += slot_b; t.far_off += far_b; t.coo_off += coo_b;
+                t.fwd_off += (uint64_t)fwd_b[(size_t)g] * 4; t.bwd_off += (uint64_t)bwd_b[(size_t)g] * 4;
+                t.row_base += (uint32_t)slot_b[(size_t)g]; t.far_off += far_b; t.coo_off += coo_b;
                 out.tiles.push_back(t);
             }
-            out.slot_row.insert(out.slot_row.end(), F.slot_row.begin(), F.slot_row.end());
-            out.fwd.insert(out.fwd.end(), F.fwd.begin(), F.fwd.end());
-            out.bwd.insert(out.bwd.end(), F.bwd.begin(), F.bwd.end());
             out.coo.insert(out.coo.end(), F.coo.begin(), F.coo.end());
             out.far_tid.insert(out.far_tid.end(), F.far_tid.begin(), F.far_tid.end());
             out.tiled_entries += F.tiled_entries; out.far_entries += F.far_entries; out.coo_entries += F.coo_entries;
             out.n_fslices += F.n_fslices; out.padded_slots += F.padded_slots;
-            F = TiledLayout();
         }
+        next.store(0);
+        auto copier = [&]() {
+            for (;;) {
+                const int64_t g = next.fetch_add(1);
+                if (g >= n_frag) break;
+                TiledLayout &F = frag[(size_t)g];
+                if (!F.slot_row.empty()) memcpy(out.slot_row.data() + slot_b[(size_t)g], F.slot_row.data(), F.slot_row.size() * sizeof(int64_t));
+                if (!F.fwd.empty()) memcpy(out.fwd.data() + fwd_b[(size_t)g], F.fwd.data(), F.fwd.size() * 4);
+                if (!F.bwd.empty()) memcpy(out.bwd.data() + bwd_b[(size_t)g], F.bwd.data(), F.bwd.size() * 4);
+                F = TiledLayout();
+            }
+        };
+        pool.clear();
+        for (int t = 1; t < nthr; t++) pool.emplace_back(copier);
+        copier();
+        for (auto &th : pool) th.join();
     }
     // Largest tiles first: they start while the grid is full, the small ones fill the tail.
     auto work = [](const Tile &t) {
