@@ -48,6 +48,8 @@ struct emsar_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    hipStream_t side[2] = {nullptr, nullptr};     // the 256- and 512-thread classes of the set solver run next to the 64-thread one
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     std::string err;
     // structure
     bool have_structure = false, have_sample = false;
@@ -374,16 +376,24 @@ int solve_resident_sets(emsar_hip_ctx *ctx, const SetSolveParams &P, double *the
     const auto &S = ctx->RS;
     hipLaunchKernelGGL(k_closed_form, dim3(grid_for(ctx->n_tx, 256)), dim3(256), 0, ctx->stream, ctx->n_tx, ctx->d_kind, ctx->d_usum,
                        ctx->d_den, theta);
-    size_t off = 0;
-#define LAUNCH_S(C, TH)                                                                                                    \
-    if (!S.desc[C].empty()) {                                                                                              \
-        hipLaunchKernelGGL(k_solve_sets<TH>, dim3((unsigned)S.desc[C].size()), dim3(TH), S.max_lds[C], ctx->stream,          \
+    // The three size classes are independent (disjoint sets, disjoint theta entries): the larger two run on side streams
+    // next to the 64-thread class, so the solve lasts as long as the slowest class, not as long as their sum.
+    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    const size_t off[3] = {0, S.desc[0].size(), S.desc[0].size() + S.desc[1].size()};      // per-set results in class order
+#define LAUNCH_S(C, TH, ST)                                                                                                \
+    if (!S.desc[C].empty())                                                                                                \
+        hipLaunchKernelGGL(k_solve_sets<TH>, dim3((unsigned)S.desc[C].size()), dim3(TH), S.max_lds[C], ST,                   \
                            ctx->d_sdesc[C], ctx->d_g_tid, ctx->d_g_u, ctx->d_row_w, ctx->d_srp, ctx->d_sent, ctx->d_scp,     \
-                           ctx->d_scrow, ctx->d_den, theta, ctx->d_sstat + off, P);                                        \
-        off += S.desc[C].size();                                                                                           \
-    }
-    LAUNCH_S(0, 64) LAUNCH_S(1, 256) LAUNCH_S(2, 512)
+                           ctx->d_scrow, ctx->d_den, theta, ctx->d_sstat + off[C], P);
+    for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0));
+    LAUNCH_S(2, 512, ctx->side[1])      // the big ones first: they are the fewest and the longest per pass
+    LAUNCH_S(1, 256, ctx->side[0])
+    LAUNCH_S(0, 64, ctx->stream)
 #undef LAUNCH_S
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipEventRecord(ctx->ev_join[i], ctx->side[i]));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
+    }
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
 }
@@ -428,6 +438,10 @@ int emsar_hip_create(emsar_hip_ctx **out, int device_id) {
     if (const char *e = getenv("EMSAR_HIP_GRAPH")) ctx->use_graph = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
+    for (int i = 0; i < 2; i++)
+        if (hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
+    if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipMalloc(&ctx->d_scal, sizeof(Scal)) != hipSuccess) return fail(EMSAR_HIP_ERR_OOM);
     if (hipHostMalloc((void **)&ctx->h_scal, sizeof(Scal), hipHostMallocDefault) != hipSuccess) return fail(EMSAR_HIP_ERR_OOM);
     // both pass kernels may need more than the default dynamic-LDS limit
@@ -445,6 +459,11 @@ void emsar_hip_destroy(emsar_hip_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
+        if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
