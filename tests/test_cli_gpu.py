@@ -79,6 +79,31 @@ def test_multisample_list(tmp_path):
         assert st["samples"] == 3 and st["failed"] == 0 and all(s["converged"] == 1 for s in st["per_sample"])
 
 
+def test_multisample_list_with_broken_samples(tmp_path):
+    """-M with a missing and an empty alignment file between good ones: the good samples are written (the alignments of
+    sample i+1 are counted while sample i is solved, so a failure surfaces one step ahead), the job reports two failures
+    and exits non-zero like the reference does on its first bad sample -- but after finishing the others."""
+    import json
+    fx = get_fixture("syn300_se")
+    empty = tmp_path / "empty.bowtie"
+    empty.write_text("")
+    lst = tmp_path / "mixed.list"
+    lst.write_text("\n".join([_aln(fx), str(tmp_path / "missing.bowtie"), _aln(fx), str(empty), _aln(fx)]) + "\n")
+    out = tmp_path / "mixed"
+    stats = tmp_path / "mixed.json"
+    r = subprocess.run([CLI, "-q", "-M", "--gpus", "1", "--stats-json", str(stats), "-I", os.path.join(fx.dir, "index.rsh"),
+                        str(out), "ms", str(lst)], capture_output=True, timeout=600)
+    assert r.returncode != 0
+    files = sorted(os.path.basename(f) for f in glob.glob(str(out / "ms.*.fpkm")))
+    assert files == ["ms.0.fpkm", "ms.2.fpkm", "ms.4.fpkm"]
+    st = json.load(open(stats))
+    assert st["samples"] == 5 and st["failed"] == 2
+    assert [int(s["status"] != 0) for s in st["per_sample"]] == [0, 1, 0, 1, 0]
+    for i in (0, 2, 4):
+        _check_fpkm_file(fx, str(out / ("ms.%d.fpkm" % i)))
+    assert b"alnfile[1]" in r.stderr and b"alnfile[3]" in r.stderr
+
+
 def test_cli_errors(tmp_path):
     fx = get_fixture("toy5_se50")
     r = subprocess.run([CLI, "-q", "-I", str(tmp_path / "nope.rsh"), str(tmp_path), "o", _aln(fx)], capture_output=True)
