@@ -51,6 +51,19 @@ __device__ __forceinline__ double wave_max_dpp(double v) {      // v >= 0
     return wave_bcast63(v);
 }
 
+// Workgroup barrier of the set solver.  A one-wave workgroup needs none: the DS operations of a wave execute in order, so
+// only the compiler has to be kept from moving LDS accesses across the point (same hand-over as between the E- and the
+// M-step of the tiled pass kernel); s_barrier would cost its issue + wait on every one of the ~10 phases of a cycle.
+template <int THREADS>
+__device__ __forceinline__ void set_sync() {
+    if (THREADS > 64) __syncthreads();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 template <int THREADS, int N>
 __device__ __forceinline__ void set_reduce_sum(double (&v)[N], double *red) {
 #pragma unroll
@@ -121,7 +134,7 @@ __device__ __forceinline__ double set_em_estep(const SetLds &L, const double *x)
         L.w[j] = live ? r * fast_rcp(S) : 0.0;
         if (LL && live) ll += r * log(S);
     }
-    __syncthreads();
+    set_sync<THREADS>();
     return ll;
 }
 __device__ __forceinline__ double set_em_acc(const SetLds &L, int i) {
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
     for (int j = threadIdx.x; j <= nr; j += THREADS) rp[j] = rp_g[d.rp_off + j];
     for (int i = threadIdx.x; i <= nt; i += THREADS) cp[i] = cp_g[d.cp_off + i];
     for (int k = threadIdx.x; k < nnz; k += THREADS) { ent[k] = ent_g[d.ent_off + k]; crow[k] = crow_g[d.ent_off + k]; }
-    __syncthreads();
+    set_sync<THREADS>();
 
     double stepmax = 1.0, delta = __builtin_huge_val();
     int passes = 0, converged = 0;
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
             dloc = fmax(dloc, dd);
         }
         delta = set_reduce_max<THREADS>(dloc, L.red);
-        __syncthreads();
+        set_sync<THREADS>();
         passes++;
         res = B;
         if (delta < P.tol) { converged = 1; break; }
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
         const bool extrap = s > 1.01;
         // extrapolated point, in place of B
         double s2[2] = {0.0, 0.0};
-        __syncthreads();
+        set_sync<THREADS>();
         for (int i = threadIdx.x; i < nt; i += THREADS) {
             const double x2 = Cc[i];
             double x = x2;
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
             B[i] = x;
             s2[1] += x * L.den[i];
         }
-        __syncthreads();
+        set_sync<THREADS>();
         // pass 3: A = EM(B) with F(B)
         s2[0] = set_em_estep<THREADS, true>(L, B);
         for (int i = threadIdx.x; i < nt; i += THREADS) {
@@ -233,13 +246,13 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
         }
         set_reduce_sum<THREADS, 2>(s2, L.red);
         const bool ok = !extrap || (s2[0] - s2[1] >= F1);
-        __syncthreads();
+        set_sync<THREADS>();
         if (!ok) {
             for (int i = threadIdx.x; i < nt; i += THREADS) A[i] = Cc[i];
             if (s >= stepmax) stepmax = fmax(1.0, stepmax / 4.0);
         }
         if ((ok ? s : 1.0) >= stepmax) stepmax *= 4.0;
-        __syncthreads();
+        set_sync<THREADS>();
         passes += 2;
         res = A;
         if (passes >= P.max_iter) break;
