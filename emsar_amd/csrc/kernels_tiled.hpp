@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
         const int d = threadIdx.x + i * kTiledThreads;
         thv[i] = 0.0; tid_d[i] = -1;
         if (d < nd) {
-            tid_d[i] = d < (int)T.near_n ? T.lo + d : far_tid[T.far_off + (d - (int)T.near_n)];
+            tid_d[i] = d < (int)T.near_n ? T.lo + d : __builtin_nontemporal_load(&far_tid[T.far_off + (d - (int)T.near_n)]);
             if (MODE != MODE_SCATTER) thv[i] = theta[tid_d[i]];
         }
     }
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
             for (int i = 0; i < kRPL; i++) r[i] = 1.0;
             if (WEIGHTED) {
 #pragma unroll
-                for (int i = 0; i < kRPL; i++) r[i] = (double)wgt[slot0 + 64 * i];
+                for (int i = 0; i < kRPL; i++) r[i] = (double)__builtin_nontemporal_load(&wgt[slot0 + 64 * i]);
             }
 #pragma unroll
             for (int i = 0; i < kRPL; i++) {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
         }
         if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
         for (unsigned q = lane; q < coo_n; q += 64) {
-            const unsigned p = coo[coo_base + q];
+            const unsigned p = __builtin_nontemporal_load(&coo[coo_base + q]);
             const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
             if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + ((p >> 16) << 3)), v);
         }
@@ -359,7 +359,7 @@ __device__ __forceinline__ void tile_dict_issue(const Tile &T, int nd, const int
         const int d = threadIdx.x + i * kTiledThreads;
         thv[i] = 0.0; tid_d[i] = -1;
         if (d < nd) {
-            tid_d[i] = d < (int)T.near_n ? T.lo + d : far_tid[T.far_off + (d - (int)T.near_n)];
+            tid_d[i] = d < (int)T.near_n ? T.lo + d : __builtin_nontemporal_load(&far_tid[T.far_off + (d - (int)T.near_n)]);
             thv[i] = theta[tid_d[i]];
         }
     }
@@ -385,7 +385,7 @@ __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], siz
     }
     if (WEIGHTED) {
 #pragma unroll
-        for (int i = 0; i < kRPL; i++) r[i] = (double)wgt[slot0 + 64 * i];
+        for (int i = 0; i < kRPL; i++) r[i] = (double)__builtin_nontemporal_load(&wgt[slot0 + 64 * i]);
     }
 #pragma unroll
     for (int i = 0; i < kRPL; i++) {
@@ -411,7 +411,7 @@ __device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], con
     }
     if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
     for (unsigned q = lane; q < W.coo_n; q += 64) {
-        const unsigned p = coo[W.coo_base + q];
+        const unsigned p = __builtin_nontemporal_load(&coo[W.coo_base + q]);
         const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
         if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + ((p >> 16) << 3)), v);
     }
