@@ -13,9 +13,16 @@ constexpr int64_t kChunkEntries = 65536;
 // ------------------------------------------------------------------------------------------------
 // device scalars of one solve (lives in HBM, polled by the host every check_every cycles)
 // ------------------------------------------------------------------------------------------------
+// A sum that hundreds of workgroups add to with same-address atomics (~10 ns each, served one after another per line)
+// gets a 128-byte line of its own: the four sums of k_update_p2 then proceed side by side in four L2 channels.
+struct alignas(128) LineF64 {
+    double v;
+    __host__ __device__ operator double() const { return v; }
+    __host__ __device__ LineF64 &operator=(double x) { v = x; return *this; }
+};
 struct Scal {
-    double ll[4];                 // sum_c R_c log S_c at the input of pass 0/1/2 of the cycle; [3] scratch
-    double sr2, sv2, pen1, penx;  // SQUAREM norms, sum theta*den of th1 and of the extrapolated point
+    LineF64 ll[4];                // sum_c R_c log S_c at the input of pass 0/1/2 of the cycle; [3] scratch
+    LineF64 sr2, sv2, pen1, penx; // SQUAREM norms, sum theta*den of th1 and of the extrapolated point
     double stepmax, s_used;
     unsigned long long delta_bits;  // max_t |dtheta|/(theta+floor) as IEEE bits (non-negative -> integer max)
     unsigned long long delta1_bits; // the same, frozen after the first (plain) pass of a SQUAREM cycle

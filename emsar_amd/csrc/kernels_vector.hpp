@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict_
 // abs_step_base > 0: the projected-drift bound of emsar_em_params.abs_step, |dtheta| < base * 2e5 / K at pass K >= 1000.  K is
 // counted here, on the device, so that a cycle recorded once in a hipGraph carries the right bound at every replay.
 __global__ void k_cycle_begin(Scal *s, double abs_step_base, int passes_in_cycle) {
-    s->ll[0] = s->ll[1] = s->ll[2] = s->ll[3] = 0.0;
-    s->sr2 = s->sv2 = s->pen1 = s->penx = 0.0;
+    for (int i = 0; i < 4; i++) s->ll[i] = 0.0;
+    s->sr2 = 0.0; s->sv2 = 0.0; s->pen1 = 0.0; s->penx = 0.0;
     s->delta_bits = 0ull; s->delta1_bits = 0ull;
     const long long done = s->passes;
     s->abs_step_cur = abs_step_base > 0.0 ? abs_step_base * 2e5 / (double)(done + 1 > 1000 ? done + 1 : 1000) : 0.0;
@@ -92,15 +92,15 @@ __global__ __launch_bounds__(256) void k_update_p2(int n, const double *__restri
     double c = block_sum<256>(p1, red); __syncthreads();
     double d = block_sum<256>(l1, red);
     if (threadIdx.x == 0) {
-        atomic_add_f64(&scal->sr2, a); atomic_add_f64(&scal->sv2, b); atomic_add_f64(&scal->pen1, c);
-        if (d != 0.0) atomic_add_f64(&scal->ll[1], d);
+        atomic_add_f64(&scal->sr2.v, a); atomic_add_f64(&scal->sv2.v, b); atomic_add_f64(&scal->pen1.v, c);
+        if (d != 0.0) atomic_add_f64(&scal->ll[1].v, d);
     }
 }
 __global__ __launch_bounds__(256) void k_sq_extrap_ll(int n, const double *__restrict__ th0, const double *__restrict__ th1,
                                                       const double *__restrict__ th2, const double *__restrict__ den, const double *__restrict__ u,
                                                       double *__restrict__ thx, Scal *scal) {
     __shared__ double red[4];
-    double s = scal->sv2 > 0.0 ? sqrt(scal->sr2 / scal->sv2) : 1.0;
+    double s = scal->sv2.v > 0.0 ? sqrt(scal->sr2.v / scal->sv2.v) : 1.0;
     s = fmin(fmax(s, 1.0), scal->stepmax);
     const bool extrap = s > 1.01;
     double px = 0, lx = 0;
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void k_sq_extrap_ll(int n, const double *__res
     double p = block_sum<256>(px, red); __syncthreads();
     double l = block_sum<256>(lx, red);
     if (threadIdx.x == 0) {
-        atomic_add_f64(&scal->penx, p);
-        if (l != 0.0) atomic_add_f64(&scal->ll[2], l);
+        atomic_add_f64(&scal->penx.v, p);
+        if (l != 0.0) atomic_add_f64(&scal->ll[2].v, l);
         if (blockIdx.x == 0) scal->s_used = extrap ? s : 1.0;
     }
 }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_update_p3(int n, const double *__restri
                                                    const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th0, Scal *scal) {
     const double s = scal->s_used;
     const bool extrap = s > 1.0;
-    const bool ok = !extrap || (scal->ll[2] - scal->penx >= scal->ll[1] - scal->pen1);
+    const bool ok = !extrap || (scal->ll[2].v - scal->penx.v >= scal->ll[1].v - scal->pen1.v);
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
         const double y = em_new_theta(thx[t], acc[t], den[t], u, t);
         acc[t] = 0.0;
