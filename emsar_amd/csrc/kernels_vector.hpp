@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_adj_euma(int64_t n_rows, int nfl, const
     for (; i + 8 <= nfl; i += 8) {
         int32_t e[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) e[j] = euma_t[(size_t)(i + j) * (size_t)n_rows + (size_t)r];
+        for (int j = 0; j < 8; j++) e[j] = __builtin_nontemporal_load(&euma_t[(size_t)(i + j) * (size_t)n_rows + (size_t)r]);   // read once per sample
 #pragma unroll
         for (int j = 0; j < 8; j++) { const double p = wf[i + j] * (double)e[j]; a = a + p; }
     }
