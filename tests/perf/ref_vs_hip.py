@@ -2,7 +2,10 @@
 """End-to-end drop-in comparison on one box: the compiled reference (oracle/_ref/emsar, CPU) against emsar-hip (GPU)
 on the same synthetic rsh + default-bowtie input.  Prints wall times of both programs and the FPKM agreement.
 
-    python tests/perf/ref_vs_hip.py [n_tx] [n_reads] [threads] [largest_family]
+    python tests/perf/ref_vs_hip.py [n_tx] [n_reads] [threads] [largest_family] [bam]
+
+With a fifth argument "bam" the same reads are handed to both programs as BAM (-B): written by the small python BGZF
+writer of tests/golden/make_golden.py, so keep n_reads moderate.
 
 The reference binary is test infrastructure (built in the build container from /root/reference by oracle/Makefile and
 shipped as a binary); it is used here only as the thing to compare against.
@@ -25,6 +28,7 @@ n_tx = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 150000
 threads = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 fam_max = int(sys.argv[4]) if len(sys.argv) > 4 else 6          # largest gene family: the reference's cost is quadratic in it
+as_bam = len(sys.argv) > 5 and sys.argv[5] == "bam"
 REF = os.path.join(ROOT, "oracle", "_ref", "emsar")
 HIP = os.path.join(ROOT, "emsar_amd", "emsar-hip")
 
@@ -35,10 +39,24 @@ with tempfile.TemporaryDirectory() as d:
     G.synth_rsh_case(d, seed=77, n_tx=n_tx, minfrag=50, maxfrag=52, n_reads=n_reads, opts=[], fam_max=fam_max, with_quirks=False)
     rsh, aln = os.path.join(d, "index.rsh"), os.path.join(d, "reads.bowtie")
     print("input: %d transcripts, %d reads, bowtie text %.1f MB" % (n_tx, n_reads, os.path.getsize(aln) / 1e6), flush=True)
+    fmt = []
+    if as_bam:
+        t0 = time.time()
+        names = [l.split("\t")[1].strip() for l in open(rsh) if l.startswith("@")]
+        sam, bam = os.path.join(d, "reads.sam"), os.path.join(d, "reads.bam")
+        with open(sam, "w") as f:
+            for n in names:
+                f.write("@SQ\tSN:%s\tLN:100000\n" % n)
+            for line in open(aln):
+                q = line.rstrip("\n").split("\t")                  # bowtie: name strand ref pos seq qual n mm
+                f.write(G.sam_line(q[0], 0 if q[1] == "+" else 16, q[2], int(q[3]), len(q[4]), str(len(q[4]))))
+        G.sam_to_bam(sam, bam)
+        aln, fmt = bam, ["-B"]
+        print("as BAM: %.1f MB (written in %.0f s)" % (os.path.getsize(bam) / 1e6, time.time() - t0), flush=True)
     res = {}
-    for name, cmd in (("reference -p 1", [REF, "-q", "-p", "1", "-I", rsh, os.path.join(d, "r1"), "o", aln]),
-                      ("reference -p %d" % threads, [REF, "-q", "-p", str(threads), "-I", rsh, os.path.join(d, "rp"), "o", aln]),
-                      ("emsar-hip", [HIP, "-q", "--stats-json", os.path.join(d, "st.json"), "-I", rsh, os.path.join(d, "h"), "o", aln])):
+    for name, cmd in (("reference -p 1", [REF, "-q", "-p", "1"] + fmt + ["-I", rsh, os.path.join(d, "r1"), "o", aln]),
+                      ("reference -p %d" % threads, [REF, "-q", "-p", str(threads)] + fmt + ["-I", rsh, os.path.join(d, "rp"), "o", aln]),
+                      ("emsar-hip", [HIP, "-q", "--stats-json", os.path.join(d, "st.json")] + fmt + ["-I", rsh, os.path.join(d, "h"), "o", aln])):
         t0 = time.time()
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         res[name] = time.time() - t0
@@ -64,7 +82,7 @@ with tempfile.TemporaryDirectory() as d:
           % (int(quiet.sum()), int(bad.sum()), float((np.abs(h - a) / np.maximum(a, 1e-300))[quiet & (a > 1)].max())))
     # the command line stops on the .fpkm print quantum (--zero-cut 2.5e-7 --abs-step 1e-13); the same input at the strict rule
     t0 = time.time()
-    subprocess.run([HIP, "-q", "--zero-cut", "0", "--abs-step", "0", "--stats-json", os.path.join(d, "st2.json"), "-I", rsh, os.path.join(d, "hs"), "o", aln],
+    subprocess.run([HIP, "-q", "--zero-cut", "0", "--abs-step", "0", "--stats-json", os.path.join(d, "st2.json")] + fmt + ["-I", rsh, os.path.join(d, "hs"), "o", aln],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     t_strict = time.time() - t0
     hs = O.read_fpkm(os.path.join(d, "hs", "o.0.fpkm"))["fpkm"]
