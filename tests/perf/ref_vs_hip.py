@@ -92,4 +92,13 @@ with tempfile.TemporaryDirectory() as d:
              float((np.abs(hs - a) / np.maximum(a, 1e-300))[quiet & (a > 1)].max())))
     print("emsar-hip print-quantum rules vs strict: %d transcripts differ beyond 1e-5 rel + 1.5e-6, largest |dFPKM| %.3e, largest rel diff on FPKM > 1: %.2e"
           % (int((np.abs(h - hs) > tol(hs)).sum()), float(np.abs(h - hs).max()), float((np.abs(h - hs) / np.maximum(hs, 1e-300))[hs > 1].max())))
-    seg = lambda p: O.read_segments(p, n_tx) if os.path.exists(p) else None
+    # the objective itself (F at the printed FPKMs; where theta is not identified, F decides): the segment
+    # Poisson log-likelihood of the sample, evaluated by the oracle at the three printed answers
+    from emsar_amd import hostlib as HL
+    hr = HL.HostRsh(rsh)
+    cnt = hr.count(aln, fmt=2 if as_bam else 0)
+    mdl = hr.model(cnt)
+    csr = O.Csr(hr.n_tx, hr.row_ptr, hr.col_idx, R=cnt.R, E=mdl.E_solver)
+    Fa, Fb, Fh, Fs = (csr.loglik(x) for x in (a, b, h, hs))
+    print("segment log-likelihood F at the printed FPKMs: reference -p 1 %.6f, -p %d %+.6f, emsar-hip %+.6f, emsar-hip strict %+.6f (differences to -p 1; higher is better)"
+          % (Fa, threads, Fb - Fa, Fh - Fa, Fs - Fa))
