@@ -1,6 +1,8 @@
 """GPU: randomised differential test -- many small, ugly matrices (empty rows, repeated ids inside a row, rows longer
 than a tile holds, cross-family rows, zero weights, rows outside the likelihood, transcripts nobody names) through every
 layout against the CPU oracle, pass by pass and to convergence."""
+import os
+
 import numpy as np
 import pytest
 
@@ -53,7 +55,7 @@ def dev():
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMSAR_RANDOM_SEEDS", "10"))))     # a longer campaign: EMSAR_RANDOM_SEEDS=60
 def test_passes_and_solve_match_the_oracle(dev, seed):
     n_tx, rp, ci, R, E = random_problem(1000 + seed)
     weighted = seed % 3 != 0
