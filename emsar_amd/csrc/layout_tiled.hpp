@@ -225,19 +225,39 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         }
     });
     std::vector<uint32_t> act;                             // the tiled rows, ascending
-    for (int64_t r = 0; r < n_rows; r++) {
-        uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-        uint64_t len = e - b;
-        if (len == 0) continue;
-        const uint32_t r_orig = merge_rows ? orig_of_merged[(size_t)r] : (uint32_t)r;   // singles / long rows are never merged
-        if (len == 1) { out.single_row.push_back(r_orig); out.single_tid.push_back(col_idx[b]); continue; }
-        if (len > (uint64_t)kMaxRowLen) {
-            out.left_row.push_back(r_orig);
-            out.left_col.insert(out.left_col.end(), col_idx + b, col_idx + e);
-            out.left_ptr.push_back((uint64_t)out.left_col.size());
-            continue;
+    {
+        // every thread classifies a contiguous range of rows into lists of its own; the lists are joined in range order
+        struct Part { std::vector<uint32_t> single_row, left_row, act; std::vector<int32_t> single_tid, left_col; std::vector<uint64_t> left_len; };
+        std::vector<Part> part((size_t)std::max(1, n_host));
+        const int np = par_ranges(n_rows, [&](int t, int64_t lo, int64_t hi) {
+            Part &P = part[(size_t)t];
+            for (int64_t r = lo; r < hi; r++) {
+                const uint64_t b = row_ptr[r], e = row_ptr[r + 1], len = e - b;
+                if (len == 0) continue;
+                const uint32_t r_orig = merge_rows ? orig_of_merged[(size_t)r] : (uint32_t)r;   // singles / long rows are never merged
+                if (len == 1) { P.single_row.push_back(r_orig); P.single_tid.push_back(col_idx[b]); continue; }
+                if (len > (uint64_t)kMaxRowLen) {
+                    P.left_row.push_back(r_orig);
+                    P.left_col.insert(P.left_col.end(), col_idx + b, col_idx + e);
+                    P.left_len.push_back(len);
+                    continue;
+                }
+                P.act.push_back((uint32_t)r);
+            }
+        });
+        size_t ns = 0, nl = 0, nlc = 0, na = 0;
+        for (int t = 0; t < np; t++) { ns += part[(size_t)t].single_row.size(); nl += part[(size_t)t].left_row.size(); nlc += part[(size_t)t].left_col.size(); na += part[(size_t)t].act.size(); }
+        out.single_row.reserve(ns); out.single_tid.reserve(ns); out.left_row.reserve(nl); out.left_col.reserve(nlc); out.left_ptr.reserve(nl + 1); act.reserve(na);
+        for (int t = 0; t < np; t++) {
+            Part &P = part[(size_t)t];
+            out.single_row.insert(out.single_row.end(), P.single_row.begin(), P.single_row.end());
+            out.single_tid.insert(out.single_tid.end(), P.single_tid.begin(), P.single_tid.end());
+            out.left_row.insert(out.left_row.end(), P.left_row.begin(), P.left_row.end());
+            out.left_col.insert(out.left_col.end(), P.left_col.begin(), P.left_col.end());
+            for (uint64_t len : P.left_len) out.left_ptr.push_back(out.left_ptr.back() + len);
+            act.insert(act.end(), P.act.begin(), P.act.end());
+            P = Part();
         }
-        act.push_back((uint32_t)r);
     }
     const int64_t n_act = (int64_t)act.size();
     // Sort granularity in tid space.  A tile's dictionary must hold a block's tid range plus the rows' reach, so
