@@ -28,6 +28,7 @@
 #include "../../include/emsar_hip.h"
 #include "internal.hpp"
 #include <cstdlib>
+#include <new>
 
 #include "layout.hpp"
 
@@ -226,7 +227,8 @@ extern "C" int emsar_hip_collapse_rows(emsar_hip_ctx *ctx, int64_t n_rows, int32
     CCHK(hipStreamSynchronize(st));
     const int64_t nu = (int64_t)last_uid + last_flag;
     const uint64_t nnz_u = last_off + last_len;
-    std::vector<long long> w64((size_t)nu);
+    std::vector<long long> w64;
+    try { w64.resize((size_t)nu); } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
     if (nu) {
         CCHK(hipMemcpyAsync(row_ptr_out, d_orp.p, (size_t)nu * 8, hipMemcpyDeviceToHost, st));
         CCHK(hipMemcpyAsync(w64.data(), d_ow.p, (size_t)nu * 8, hipMemcpyDeviceToHost, st));

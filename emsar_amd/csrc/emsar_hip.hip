@@ -288,45 +288,47 @@ struct CycleGraph {
 
 // scatter a per-row value (original row order, host) to its columns: out[t] = sum_c m_ct val[c]
 int scatter_rows(emsar_hip_ctx *ctx, const double *val_host, double *d_out) {
-    if (ctx->layout == EMSAR_LAYOUT_TILED) {
-        const auto &L = ctx->TL;
-        std::vector<double> slot((size_t)std::max<int64_t>(ctx->n_slots, 1), 0.0), left((size_t)std::max<int64_t>(ctx->n_left, 1), 0.0);
-        std::vector<double> base((size_t)ctx->n_tx, 0.0);
-        for (int64_t i = 0; i < ctx->n_slots; i++) {
-            int64_t r = L.slot_row[(size_t)i];
-            if (r < 0) continue;
-            if (L.merged) { double v = 0; for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) v += val_host[L.mem_row[(size_t)q]]; slot[(size_t)i] = v; }
-            else slot[(size_t)i] = val_host[r];
+    try {
+        if (ctx->layout == EMSAR_LAYOUT_TILED) {
+            const auto &L = ctx->TL;
+            std::vector<double> slot((size_t)std::max<int64_t>(ctx->n_slots, 1), 0.0), left((size_t)std::max<int64_t>(ctx->n_left, 1), 0.0);
+            std::vector<double> base((size_t)ctx->n_tx, 0.0);
+            for (int64_t i = 0; i < ctx->n_slots; i++) {
+                int64_t r = L.slot_row[(size_t)i];
+                if (r < 0) continue;
+                if (L.merged) { double v = 0; for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) v += val_host[L.mem_row[(size_t)q]]; slot[(size_t)i] = v; }
+                else slot[(size_t)i] = val_host[r];
+            }
+            for (int64_t i = 0; i < ctx->n_left; i++) left[(size_t)i] = val_host[L.left_row[(size_t)i]];
+            for (size_t i = 0; i < L.single_row.size(); i++) base[(size_t)L.single_tid[i]] += val_host[L.single_row[i]];
+            if (!ctx->d_rowval) HIPCHK(hipMalloc(&ctx->d_rowval, slot.size() * sizeof(double)));
+            if (!ctx->d_left_val) HIPCHK(hipMalloc(&ctx->d_left_val, left.size() * sizeof(double)));
+            HIPCHK(hipMemcpyAsync(ctx->d_rowval, slot.data(), slot.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(ctx->d_left_val, left.data(), left.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(d_out, base.data(), base.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            int rc = launch_pass(ctx, MODE_SCATTER, nullptr, d_out, nullptr);
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            return EMSAR_HIP_OK;
         }
-        for (int64_t i = 0; i < ctx->n_left; i++) left[(size_t)i] = val_host[L.left_row[(size_t)i]];
-        for (size_t i = 0; i < L.single_row.size(); i++) base[(size_t)L.single_tid[i]] += val_host[L.single_row[i]];
-        if (!ctx->d_rowval) HIPCHK(hipMalloc(&ctx->d_rowval, slot.size() * sizeof(double)));
-        if (!ctx->d_left_val) HIPCHK(hipMalloc(&ctx->d_left_val, left.size() * sizeof(double)));
-        HIPCHK(hipMemcpyAsync(ctx->d_rowval, slot.data(), slot.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(ctx->d_left_val, left.data(), left.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(d_out, base.data(), base.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        std::vector<double> tmp;
+        const double *src = val_host;
+        size_t n = (size_t)ctx->n_rows;
+        if (ctx->layout == EMSAR_LAYOUT_WINDOWED) {
+            n = (size_t)ctx->padded_rows;
+            tmp.assign(n, 0.0);
+            for (int64_t i = 0; i < ctx->L.n_sorted_rows; i++) tmp[(size_t)i] = val_host[ctx->L.perm[(size_t)i]];
+            src = tmp.data();
+        }
+        if (n == 0) return EMSAR_HIP_OK;
+        if (!ctx->d_rowval) HIPCHK(hipMalloc(&ctx->d_rowval, std::max<size_t>(n, 1) * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(ctx->d_rowval, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(d_out, 0, (size_t)ctx->n_tx * sizeof(double), ctx->stream));
         int rc = launch_pass(ctx, MODE_SCATTER, nullptr, d_out, nullptr);
         if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // tmp must outlive the copy
         return EMSAR_HIP_OK;
-    }
-    std::vector<double> tmp;
-    const double *src = val_host;
-    size_t n = (size_t)ctx->n_rows;
-    if (ctx->layout == EMSAR_LAYOUT_WINDOWED) {
-        n = (size_t)ctx->padded_rows;
-        tmp.assign(n, 0.0);
-        for (int64_t i = 0; i < ctx->L.n_sorted_rows; i++) tmp[(size_t)i] = val_host[ctx->L.perm[(size_t)i]];
-        src = tmp.data();
-    }
-    if (n == 0) return EMSAR_HIP_OK;
-    if (!ctx->d_rowval) HIPCHK(hipMalloc(&ctx->d_rowval, std::max<size_t>(n, 1) * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(ctx->d_rowval, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(d_out, 0, (size_t)ctx->n_tx * sizeof(double), ctx->stream));
-    int rc = launch_pass(ctx, MODE_SCATTER, nullptr, d_out, nullptr);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));  // tmp must outlive the copy
-    return EMSAR_HIP_OK;
+    } catch (const std::bad_alloc &) { ctx->err = "out of host memory"; return EMSAR_HIP_ERR_OOM; }
 }
 
 // find and pack the connected sets of the current sample (sets.hpp) and move the records to the device
@@ -964,19 +966,21 @@ int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *o) {
 // Builds the layout for the given CSR, decodes it again and compares; fills *info_out (may be NULL).
 int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                                int32_t window, int64_t chunk_entries, emsar_hip_info *info_out) {
-    if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
-    emsar::WindowedLayout L;
-    if (window <= 0) window = kDefaultWindow;
-    if (chunk_entries <= 0) chunk_entries = kChunkEntries;
-    if (emsar::build_windowed(n_rows, n_tx, row_ptr, col_idx, window, chunk_entries, L) != 0) return EMSAR_HIP_ERR_ARG;
-    int rc = emsar::check_windowed(L, row_ptr, col_idx);
-    if (info_out) {
-        memset(info_out, 0, sizeof(*info_out));
-        info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx; info_out->layout = EMSAR_LAYOUT_WINDOWED;
-        info_out->n_chunks = (int64_t)L.chunks.size(); info_out->n_slices = L.n_slices();
-        info_out->padded_entries = (int64_t)L.slice_off.back(); info_out->far_entries = L.far_entries; info_out->window = window;
-    }
-    return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
+    try {
+        if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
+        emsar::WindowedLayout L;
+        if (window <= 0) window = kDefaultWindow;
+        if (chunk_entries <= 0) chunk_entries = kChunkEntries;
+        if (emsar::build_windowed(n_rows, n_tx, row_ptr, col_idx, window, chunk_entries, L) != 0) return EMSAR_HIP_ERR_ARG;
+        int rc = emsar::check_windowed(L, row_ptr, col_idx);
+        if (info_out) {
+            memset(info_out, 0, sizeof(*info_out));
+            info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx; info_out->layout = EMSAR_LAYOUT_WINDOWED;
+            info_out->n_chunks = (int64_t)L.chunks.size(); info_out->n_slices = L.n_slices();
+            info_out->padded_entries = (int64_t)L.slice_off.back(); info_out->far_entries = L.far_entries; info_out->window = window;
+        }
+        return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
+    } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }     // nothing may leave the C ABI as an exception
 }
 
 // Diagnostic only (not declared in the public header): one stamped pass of the TILED kernel on the current theta.
@@ -1010,42 +1014,46 @@ int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
 
 int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                                      int merge_rows, emsar_hip_info *info_out) {
-    if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
-    emsar::TiledLayout L;
-    if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows != 0) != 0) return EMSAR_HIP_ERR_ARG;
-    int rc = emsar::check_tiled(L, row_ptr, col_idx);
-    if (info_out) {
-        memset(info_out, 0, sizeof(*info_out));
-        info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx;
-        info_out->layout = EMSAR_LAYOUT_TILED | (L.merged ? EMSAR_LAYOUT_FLAG_MERGE_ROWS : 0);
-        info_out->n_chunks = (int64_t)L.tiles.size();
-        info_out->n_slices = L.n_fslices;
-        info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries; info_out->window = emsar::kTileDict;
-        info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 +
-                                          (int64_t)L.far_tid.size() * 4 + (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4;
-        info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
-    }
-    return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
+    try {
+        if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
+        emsar::TiledLayout L;
+        if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows != 0) != 0) return EMSAR_HIP_ERR_ARG;
+        int rc = emsar::check_tiled(L, row_ptr, col_idx);
+        if (info_out) {
+            memset(info_out, 0, sizeof(*info_out));
+            info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx;
+            info_out->layout = EMSAR_LAYOUT_TILED | (L.merged ? EMSAR_LAYOUT_FLAG_MERGE_ROWS : 0);
+            info_out->n_chunks = (int64_t)L.tiles.size();
+            info_out->n_slices = L.n_fslices;
+            info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries; info_out->window = emsar::kTileDict;
+            info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 +
+                                              (int64_t)L.far_tid.size() * 4 + (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4;
+            info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
+        }
+        return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
+    } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }     // nothing may leave the C ABI as an exception
 }
 
 int emsar_hip_sets_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                              const int32_t *row_weight, emsar_hip_sets_info *o) {
-    if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
-    if (row_weight) for (int64_t r = 0; r < n_rows; r++) if (row_weight[r] < 0) return EMSAR_HIP_ERR_ARG;
-    emsar::ResidentSets S;
     try {
-        emsar::build_sets(n_rows, n_tx, row_ptr, col_idx, row_weight, S);
-    } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
-    int rc = emsar::check_sets(n_rows, n_tx, row_ptr, col_idx, row_weight, S);
-    if (o) {
-        memset(o, 0, sizeof(*o));
-        o->n_components = S.n_components;
-        for (int c = 0; c < emsar::kSetClasses; c++) { o->sets_resident[c] = (int64_t)S.desc[c].size(); o->max_lds_bytes[c] = (int64_t)S.max_lds[c]; }
-        o->sets_streamed = S.n_streamed_sets;
-        o->tids_closed = S.n_closed_tids; o->tids_resident = S.n_resident_tids; o->tids_streamed = S.n_streamed_tids;
-        o->rows_in = S.rows_in; o->rows_stored = S.rows_stored;
-    }
-    return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 200 + rc;
+        if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
+        if (row_weight) for (int64_t r = 0; r < n_rows; r++) if (row_weight[r] < 0) return EMSAR_HIP_ERR_ARG;
+        emsar::ResidentSets S;
+        try {
+            emsar::build_sets(n_rows, n_tx, row_ptr, col_idx, row_weight, S);
+        } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
+        int rc = emsar::check_sets(n_rows, n_tx, row_ptr, col_idx, row_weight, S);
+        if (o) {
+            memset(o, 0, sizeof(*o));
+            o->n_components = S.n_components;
+            for (int c = 0; c < emsar::kSetClasses; c++) { o->sets_resident[c] = (int64_t)S.desc[c].size(); o->max_lds_bytes[c] = (int64_t)S.max_lds[c]; }
+            o->sets_streamed = S.n_streamed_sets;
+            o->tids_closed = S.n_closed_tids; o->tids_resident = S.n_resident_tids; o->tids_streamed = S.n_streamed_tids;
+            o->rows_in = S.rows_in; o->rows_stored = S.rows_stored;
+        }
+        return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 200 + rc;
+    } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }     // nothing may leave the C ABI as an exception
 }
 
 }  // extern "C"

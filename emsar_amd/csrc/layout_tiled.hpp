@@ -32,6 +32,8 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <new>
+#include <system_error>
 #include <utility>
 #include <vector>
 
@@ -104,6 +106,24 @@ struct TiledLayout {
     int64_t tiled_entries = 0, far_entries = 0, coo_entries = 0, n_fslices = 0, padded_slots = 0;
     int64_t n_slots() const { return (int64_t)slot_row.size(); }
 };
+
+// fn(0) on the calling thread, fn(1..nt-1) on threads of their own.  An allocation failure inside a thread must not end the
+// process (an exception that leaves a std::thread calls std::terminate): it is caught there and rethrown here after the
+// joins, where emsar_hip_upload_structure turns it into EMSAR_HIP_ERR_OOM.  A thread that cannot be started runs inline.
+template <class F>
+inline void run_on_threads(int nt, F fn) {
+    std::atomic<bool> oom{false};
+    auto guarded = [&](int t) { try { fn(t); } catch (const std::bad_alloc &) { oom.store(true); } };
+    std::vector<std::thread> pool;
+    std::vector<int> inline_ids;
+    for (int t = 1; t < nt; t++) {
+        try { pool.emplace_back(guarded, t); } catch (const std::system_error &) { inline_ids.push_back(t); }
+    }
+    guarded(0);
+    for (int t : inline_ids) guarded(t);
+    for (auto &th : pool) th.join();
+    if (oom.load()) throw std::bad_alloc();
+}
 
 // With merge_rows, rows with the same tid multiset (2..kMaxRowLen tids) are stored once and weighted by the sum of
 // their members' weights -- what the reference's update_ReadCounts does when it counts reads per segment
@@ -194,10 +214,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     }
     auto par_ranges = [&](int64_t n, const std::function<void(int, int64_t, int64_t)> &fn) {
         const int nt = (int)std::min<int64_t>(n_host, std::max<int64_t>(1, n / min_chunk));
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; t++) pool.emplace_back(fn, t, n * t / nt, n * (t + 1) / nt);
-        fn(0, 0, n / nt);
-        for (auto &th : pool) th.join();
+        run_on_threads(nt, [&](int t) { fn(t, n * t / nt, n * (t + 1) / nt); });
         return nt;
     };
     std::vector<int32_t> mintid((size_t)n_rows, -1);      // the anchor tid of every tiled row (see below)
@@ -280,16 +297,12 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         const int nc = (int)std::min<int64_t>(n_host, std::max<int64_t>(1, n / min_chunk));
         std::vector<std::vector<uint64_t>> hist((size_t)nc);
         auto chunk = [&](int c) { return std::make_pair(n * c / nc, n * (c + 1) / nc); };
-        std::vector<std::thread> pool;
         auto count = [&](int c) {
             hist[(size_t)c].assign(n_keys, 0);
             auto [lo, hi] = chunk(c);
             for (int64_t i = lo; i < hi; i++) hist[(size_t)c][key(in[(size_t)i])]++;
         };
-        for (int c = 1; c < nc; c++) pool.emplace_back(count, c);
-        count(0);
-        for (auto &th : pool) th.join();
-        pool.clear();
+        run_on_threads(nc, count);
         uint64_t run = 0;
         for (size_t k = 0; k < n_keys; k++)
             for (int c = 0; c < nc; c++) { const uint64_t h = hist[(size_t)c][k]; hist[(size_t)c][k] = run; run += h; }
@@ -298,9 +311,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             uint64_t *off = hist[(size_t)c].data();
             for (int64_t i = lo; i < hi; i++) { const uint32_t r = in[(size_t)i]; dst[(size_t)off[key(r)]++] = r; }
         };
-        for (int c = 1; c < nc; c++) pool.emplace_back(scatter, c);
-        scatter(0);
-        for (auto &th : pool) th.join();
+        run_on_threads(nc, scatter);
     };
     std::vector<uint32_t> pa, perm;
     {
@@ -498,10 +509,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 frc[(size_t)g] = form_tiles(g * frag_rows, std::min(n_act, (g + 1) * frag_rows), frag[(size_t)g]);
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nthr; t++) pool.emplace_back(worker);
-        worker();
-        for (auto &th : pool) th.join();
+        run_on_threads(nthr, [&](int) { worker(); });
         for (int64_t g = 0; g < n_frag; g++) if (frc[(size_t)g] != 0) return frc[(size_t)g];
         const auto tp3 = t_now();
         if (dbg_t) fprintf(stderr, "build_tiled: classify %.0f ms, sort %.0f ms, tiles %.0f ms on %d thread(s)\n", t_ms(tp0, tp1), t_ms(tp1, tp2), t_ms(tp2, tp3), nthr);
@@ -546,10 +554,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 F = TiledLayout();
             }
         };
-        pool.clear();
-        for (int t = 1; t < nthr; t++) pool.emplace_back(copier);
-        copier();
-        for (auto &th : pool) th.join();
+        run_on_threads(nthr, [&](int) { copier(); });
     }
     // Largest tiles first: they start while the grid is full, the small ones fill the tail.
     auto work = [](const Tile &t) {
