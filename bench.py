@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads and transcripts (debug only)")
     ap.add_argument("--layout", default="auto", choices=["auto", "csr", "windowed", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--xfam", type=float, default=None, help="experiment: override the config's share of cross-family reads")
     ap.add_argument("--merge-rows", action="store_true",
                     help="store identical rows once (read -> segment collapse at upload); NOT the headline configuration")
     ap.add_argument("--solve", type=float, default=0.0, metavar="TOL",
@@ -64,6 +65,8 @@ def main():
     # ---- workload: one independent sample per rank ------------------------------------------------------
     cfg = dict(synth.CONFIGS[args.config])
     cfg["seed"] = cfg["seed"] + 100 * rank
+    if args.xfam is not None:
+        cfg["xfam"] = args.xfam
     if args.scale != 1.0:
         cfg["n_reads"] = max(1000, int(cfg["n_reads"] * args.scale))
         cfg["n_tx"] = max(500, int(cfg["n_tx"] * args.scale))

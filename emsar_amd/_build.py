@@ -26,7 +26,7 @@ CLI = os.path.join(PKG, "emsar-hip")
 
 HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-std=c++17", "-fPIC", "-shared",
              "-Wall", "-Wextra", "-Wno-unused-value"]
-HOST_SRC = ["rsh.c", "align.c", "model.c", "output.c", "pbgzf.c"]
+HOST_SRC = ["rsh.c", "align.c", "model.c", "output.c", "pbgzf.c", "hostutil.c"]
 C_FLAGS = ["-O2", "-std=c11", "-fPIC", "-Wall", "-Wextra", "-D_POSIX_C_SOURCE=200809L"]
 
 

@@ -332,13 +332,19 @@ int scatter_rows(emsar_hip_ctx *ctx, const double *val_host, double *d_out) {
 }
 
 // find and pack the connected sets of the current sample (sets.hpp) and move the records to the device
+int ensure_sets_impl(emsar_hip_ctx *ctx);
 int ensure_sets(emsar_hip_ctx *ctx) {
     if (ctx->sets_ready) return EMSAR_HIP_OK;
+    const int rc = ensure_sets_impl(ctx);
+    if (rc != EMSAR_HIP_OK) free_sets(ctx);       // a half-uploaded record set is freed, the next solve starts over
+    return rc;
+}
+int ensure_sets_impl(emsar_hip_ctx *ctx) {
     auto t0 = std::chrono::steady_clock::now();
     auto &S = ctx->RS;
     try {
         emsar::build_sets(ctx->n_rows, ctx->n_tx, ctx->h_row_ptr.data(), ctx->h_col.data(), ctx->h_wgt.data(), S);
-    } catch (const std::bad_alloc &) { free_sets(ctx); return EMSAR_HIP_ERR_OOM; }
+    } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
     auto up = [&](void **dp, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dp, std::max<size_t>(bytes, 16));
         if (e == hipSuccess && bytes) e = hipMemcpy(*dp, src, bytes, hipMemcpyHostToDevice);
@@ -600,16 +606,21 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const int64_t n_rows = ctx->n_rows;
-    // a row counts w = R (or 1) when it is inside the likelihood (E != 0), else 0
-    ctx->weighted = (row_weight != nullptr) || (row_E != nullptr) || (ctx->layout == EMSAR_LAYOUT_TILED && ctx->TL.merged);
-    ctx->loglik_const = 0.0;
-    dfree(ctx->d_wgt); ctx->d_wgt = nullptr;
+    // arguments first: a rejected call changes nothing
     if (row_weight || row_E) {
         for (int64_t r = 0; r < n_rows; r++) {
             if (row_weight && row_weight[r] < 0) return EMSAR_HIP_ERR_ARG;
             if (row_E && !(row_E[r] >= 0.0)) return EMSAR_HIP_ERR_ARG;  // negative or NaN
         }
     }
+    if (den) for (int32_t t = 0; t < ctx->n_tx; t++) if (!(den[t] >= 0.0)) return EMSAR_HIP_ERR_ARG;
+    // from here on the previous sample is gone: a call that fails half way (out of memory, HIP error) must not leave a
+    // context that still says have_sample with its weight arrays freed (run_passes would launch kernels on null pointers)
+    ctx->have_sample = false;
+    // a row counts w = R (or 1) when it is inside the likelihood (E != 0), else 0
+    ctx->weighted = (row_weight != nullptr) || (row_E != nullptr) || (ctx->layout == EMSAR_LAYOUT_TILED && ctx->TL.merged);
+    ctx->loglik_const = 0.0;
+    dfree(ctx->d_wgt); ctx->d_wgt = nullptr;
     auto weight_of = [&](int64_t r) -> int32_t {
         int32_t x = row_weight ? row_weight[r] : 1;
         if (row_E && row_E[r] == 0.0) x = 0;
@@ -678,7 +689,6 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
         HIPCHK(hipMemcpy(ctx->d_wgt, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     }
     if (den) {
-        for (int32_t t = 0; t < ctx->n_tx; t++) if (!(den[t] >= 0.0)) return EMSAR_HIP_ERR_ARG;
         HIPCHK(hipMemcpy(ctx->d_den, den, (size_t)ctx->n_tx * 8, hipMemcpyHostToDevice));
     } else {
         std::vector<double> ones;
@@ -743,9 +753,15 @@ int emsar_hip_run_passes(emsar_hip_ctx *ctx, int32_t n_passes, float *elapsed_ms
     return EMSAR_HIP_OK;
 }
 
+static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_out, emsar_em_stats *stats);
 int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_out, emsar_em_stats *stats) {
     if (!ctx || !fpkm_out) return EMSAR_HIP_ERR_ARG;
     if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
+    const int rc = solve_impl(ctx, pp, fpkm_out, stats);
+    ctx->count_floor = 0.0; ctx->zero_cut = 0.0; ctx->delta_mask = nullptr;      // per-solve state, whatever the exit
+    return rc;
+}
+static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_out, emsar_em_stats *stats) {
     emsar_em_params p = pp ? *pp : emsar_em_params{0, 1, 0, 0, 0, 0, 0, 0, 0};
     if (p.max_iter <= 0) p.max_iter = 100000;
     if (p.tol <= 0) p.tol = 1e-10;

@@ -487,13 +487,7 @@ static int plan_ranges(const char *path, const emsar_aln_opts *o, int64_t *size_
     return nt;
 }
 
-static int host_threads(void) {
-    long nc = sysconf(_SC_NPROCESSORS_ONLN);
-    int nt = nc > 16 ? 16 : nc < 1 ? 1 : (int)nc;
-    const char *e = getenv("EMSAR_HOST_THREADS");
-    if (e && atoi(e) > 0) nt = atoi(e) > 64 ? 64 : atoi(e);
-    return nt;
-}
+static int host_threads(void) { return emsar_host_threads(); }
 
 static void counts_add(emsar_counts *c, const emsar_counts *q) {
     for (int64_t i = 0; i < c->n_rows; i++) c->R[i] += q->R[i];

@@ -6,8 +6,8 @@
  *
  * Same option letters as the reference for everything that reaches this path (emsar_main.c:100-214):
  *   -I rsh  -P  -s strand  -k max_repeat  -n rounds  -e tol  -i max_passes  -d delta  -g  -M  -S  -B  -q  -v  -p threads(ignored)
- * plus  --gpus N (devices used by -M, default all), --device D (single sample), --plain (no SQUAREM),
- *       --stats-json FILE.
+ * plus  --gpus N (devices used by -M, default all), --devices a,b,.. (one -M worker per entry; an id may repeat, so that
+ *       several workers share one card), --device D (single sample), --plain (no SQUAREM), --stats-json FILE.
  * Not taken over: -x fasta (index build, emsar-build's job), -m positional bias
  * (unfinished in the reference, emsar_main.c:371), -F/-f (the reference overwrites both from the rsh header,
  * emsar_functions.c:1419-1420, so they have no effect with -I).
@@ -26,8 +26,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <errno.h>
 #include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "../../../include/emsar_hip.h"
 #include "emsar_host.h"
@@ -50,6 +52,8 @@ typedef struct {
     int *status;          /* per sample */
     emsar_em_stats *stats; /* per sample */
     double *parse_s;
+    double *model_s, *host_s;   /* per sample: model preparation, and all host work of run_sample outside the library calls */
+    int *go;              /* start gate: the workers wait until main() knows how many of them exist */
 } worker_arg;
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -96,14 +100,30 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i, parse_job *parse
         } else { free(Ldev); Ldev = NULL; }            /* model_build reports the empty fragment-length window */
         free(wf);
     }
-    /* model preparation in sample order (EUMAcut carries over) */
+    /* Model preparation.  EUMAcut carries over in sample order (emsar_main.c:95,418: never reset), but it only ever changes
+     * when a set exceeds 5000 transcripts (emsar_main.c:417-423).  So every worker builds its model at once, without the
+     * lock, from the value it sees now; at its turn in the sample order it checks that the samples before it have left
+     * that value in place and publishes its own (possibly raised) one.  Only if an earlier sample did raise the cut in
+     * the meantime is the model rebuilt, at the turn, from the value that sample left. */
+    double t_model = now_s();
+    pthread_mutex_lock(w->mu);
+    const double cut_seen = *w->eumacut;
+    pthread_mutex_unlock(w->mu);
+    double cut_mine = cut_seen;
+    if (rc == 0) rc = emsar_model_build_L(r, cnt, cfg->delta, &cut_mine, Ldev, &m, err, sizeof err);
     pthread_mutex_lock(w->mu);
     while (*w->next_model != i) pthread_cond_wait(w->cv, w->mu);
-    if (rc == 0) rc = emsar_model_build_L(r, cnt, cfg->delta, w->eumacut, Ldev, &m, err, sizeof err);
+    if (rc == 0 && *w->eumacut != cut_seen) {
+        emsar_model_free(m); m = NULL;
+        cut_mine = *w->eumacut;
+        rc = emsar_model_build_L(r, cnt, cfg->delta, &cut_mine, Ldev, &m, err, sizeof err);
+    }
+    if (rc == 0) *w->eumacut = cut_mine;
     (*w->next_model)++;
     pthread_cond_broadcast(w->cv);
     pthread_mutex_unlock(w->mu);
     free(Ldev);
+    w->model_s[i] = now_s() - t_model;
     if (rc) { fprintf(stderr, "alnfile[%d]=%s: %s\n", i, cfg->aln[i], err); goto done; }
     if (cfg->verbose > 0)
         fprintf(stdout, "alnfile[%d]=%s  reads=%lld (seen %lld, >k %lld, bad fraglen %lld, discrepant %lld, no segment %lld)  sets=%d  gpu=%d\n",
@@ -120,12 +140,14 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i, parse_job *parse
     emsar_em_params p = {cfg->max_iter, cfg->accel, cfg->tol, 0.0, 0, cfg->set_mode, cfg->count_floor, cfg->zero_cut, cfg->abs_step};
     /* den_t = sum_c m_ct E_c in row order on the host: the device's own scatter adds with atomics, whose order (and with it
      * the last bits of den, of theta and now and then the sixth printed decimal) changes from run to run */
+    double t_host = now_s();
     den = (double *)calloc(T, sizeof(double));
     if (!den) { rc = EMSAR_HOST_ERR_OOM; goto done; }
     for (int64_t c = 0; c < r->n_rows; c++) {
         const double e = m->E_solver[c];
         if (e != 0.0) for (uint64_t k = r->row_ptr[c]; k < r->row_ptr[c + 1]; k++) den[r->col_idx[k]] += e;
     }
+    w->host_s[i] = w->model_s[i] + (now_s() - t_host);
     if ((rc = emsar_hip_upload_sample(ctx, cnt->R, m->E_solver, den)) ||
         (rc = emsar_hip_solve(ctx, &p, theta, &w->stats[i]))) {
         fprintf(stderr, "alnfile[%d]: %s (%s)\n", i, emsar_hip_strerror(rc), emsar_hip_last_error(ctx));
@@ -140,6 +162,7 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i, parse_job *parse
         goto done;
     }
     int64_t tot = 0;
+    t_host = now_s();
     snprintf(path, sizeof path, "%s/%s.%d.fpkm", cfg->outdir, cfg->prefix, i);
     if ((rc = emsar_write_fpkm(path, r, mean, sd, ieuma, ir, iri, tpm, &tot))) { fprintf(stderr, "can't write %s\n", path); goto done; }
     if (cfg->verbose > 0) fprintf(stdout, "Total inferred readcount=%lld\n", (long long)tot);
@@ -149,6 +172,7 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i, parse_job *parse
         snprintf(path, sizeof path, "%s/%s.%d.segments", cfg->outdir, cfg->prefix, i);
         if ((rc = emsar_write_segments(path, r, cnt, m, mean))) { fprintf(stderr, "can't write %s\n", path); goto done; }
     }
+    w->host_s[i] += now_s() - t_host;
     if (cfg->verbose > 0)
         fprintf(stdout, "Complete: %s/%s.%d.fpkm  (EM passes %d, converged %d, solve %.1f ms, logL %.6f)\n", cfg->outdir, cfg->prefix, i,
                 w->stats[i].iters, w->stats[i].converged, w->stats[i].solve_ms, w->stats[i].loglik);
@@ -164,6 +188,9 @@ static void *worker_main(void *a) {
     parse_job slot[2];                                               /* the sample in hand and the one being counted ahead */
     int c = 0;
     memset(slot, 0, sizeof slot);
+    pthread_mutex_lock(w->mu);
+    while (!*w->go) pthread_cond_wait(w->cv, w->mu);                 /* n_workers is final from here on */
+    pthread_mutex_unlock(w->mu);
     if (w->worker < w->cfg->n_aln) parse_start(&slot[c], w, w->worker);
     int rc = emsar_hip_create(&ctx, w->device);
     if (rc == 0) rc = emsar_hip_upload_structure(ctx, w->rsh->n_rows, w->rsh->n_tx, w->rsh->row_ptr, w->rsh->col_idx, EMSAR_LAYOUT_AUTO);
@@ -209,7 +236,8 @@ static void usage(const char *a0) {
             "      --abs-step <x>        components that move by less than x FPKM per pass count as converged (default 1e-13; 0 = off)\n"
             "      --rsh-cache[=file]    read the parsed index from a binary cache (default <rshfile>.bin), write it after a text parse\n"
             "      --streaming-only      do not split the problem into connected sets (every pass streams the whole matrix)\n"
-            "      --gpus <n> / --device <d> / --plain / --stats-json <file> / -q / -v\n", a0);
+            "      --gpus <n> / --devices <a,b,..> (-M: one worker per entry, ids may repeat) / --device <d> / --plain /\n"
+            "      --stats-json <file> / -q / -v\n", a0);
 }
 
 int main(int argc, char **argv) {
@@ -218,6 +246,7 @@ int main(int argc, char **argv) {
     cfg.zero_cut = 2.5e-7;      /* a quarter of the "%lf" print quantum of the .fpkm file */
     cfg.abs_step = 1e-13;       /* see emsar_em_params.abs_step */
     const char *strand = "ns"; int multisample = 0, gpus = 0, device = 0;
+    int dev_map[64], n_dev_map = 0;
     static struct option lo[] = {
         {"rsh", required_argument, 0, 'I'}, {"PE", no_argument, 0, 'P'}, {"strand_type", required_argument, 0, 's'},
         {"maxthread", required_argument, 0, 'p'}, {"max_repeat", required_argument, 0, 'k'}, {"nround", required_argument, 0, 'n'},
@@ -225,7 +254,7 @@ int main(int argc, char **argv) {
         {"print_segments", no_argument, 0, 'g'}, {"multisample", no_argument, 0, 'M'}, {"SAM", no_argument, 0, 'S'}, {"BAM", no_argument, 0, 'B'},
         {"verbose", no_argument, 0, 'v'}, {"no_verbose", no_argument, 0, 'q'}, {"gpus", required_argument, 0, 1000},
         {"device", required_argument, 0, 1001}, {"plain", no_argument, 0, 1002}, {"stats-json", required_argument, 0, 1003},
-        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005}, {"rsh-cache", optional_argument, 0, 1006}, {"zero-cut", required_argument, 0, 1007}, {"abs-step", required_argument, 0, 1008},
+        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005}, {"rsh-cache", optional_argument, 0, 1006}, {"zero-cut", required_argument, 0, 1007}, {"abs-step", required_argument, 0, 1008}, {"devices", required_argument, 0, 1009},
         {"maxfraglen", required_argument, 0, 'F'}, {"minfraglen", required_argument, 0, 'f'}, {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "vqPs:p:F:f:n:e:d:gMSBk:i:I:", lo, NULL)) != -1) {
@@ -255,6 +284,18 @@ int main(int argc, char **argv) {
             case 1006: cfg.rsh_cache = optarg ? optarg : ""; break;
             case 1007: cfg.zero_cut = atof(optarg); break;
             case 1008: cfg.abs_step = atof(optarg); break;
+            case 1009: {
+                const char *q = optarg;
+                while (*q && n_dev_map < 64) {
+                    char *end; long d = strtol(q, &end, 10);
+                    if (end == q || d < 0 || d > 1023) { fprintf(stderr, "--devices wants a comma-separated list of device ids.\n"); return 1; }
+                    dev_map[n_dev_map++] = (int)d;
+                    q = *end == ',' ? end + 1 : end;
+                    if (*end && *end != ',') { fprintf(stderr, "--devices wants a comma-separated list of device ids.\n"); return 1; }
+                }
+                if (!n_dev_map) { fprintf(stderr, "--devices wants a comma-separated list of device ids.\n"); return 1; }
+                break;
+            }
             default: usage(argv[0]); return 1;
         }
     }
@@ -279,7 +320,21 @@ int main(int argc, char **argv) {
         if (!n_list) { fprintf(stderr, "No alignment files in the alignment list\n"); return 1; }
     }
     cfg.aln = list; cfg.n_aln = n_list;
-    mkdir(cfg.outdir, 0777);
+    /* the reference runs `mkdir -p outdir` (emsar_main.c:284-285); find out now, not after the solve, that it cannot be written */
+    {
+        char tmp[4096];
+        size_t n = strlen(cfg.outdir);
+        if (n == 0 || n >= sizeof tmp) { fprintf(stderr, "can't create output directory %s\n", cfg.outdir); return 1; }
+        memcpy(tmp, cfg.outdir, n + 1);
+        for (size_t k = 1; k <= n; k++)
+            if (tmp[k] == '/' || tmp[k] == 0) {
+                const char keep = tmp[k];
+                tmp[k] = 0;
+                if (mkdir(tmp, 0777) != 0 && errno != EEXIST) { fprintf(stderr, "can't create output directory %s\n", tmp); return 1; }
+                tmp[k] = keep;
+            }
+        if (access(cfg.outdir, W_OK | X_OK) != 0) { fprintf(stderr, "can't write to output directory %s\n", cfg.outdir); return 1; }
+    }
 
     char err[512];
     emsar_rsh *rsh = NULL;
@@ -310,7 +365,15 @@ int main(int argc, char **argv) {
         int avail = 0;
         for (int d = 0; d < 64; d++) { emsar_hip_ctx *probe = NULL; if (emsar_hip_create(&probe, d) != 0) break; emsar_hip_destroy(probe); avail++; }
         if (avail == 0) { fprintf(stderr, "%s\n", emsar_hip_strerror(EMSAR_HIP_ERR_NO_DEVICE)); return 1; }
-        n_workers = gpus > 0 && gpus < avail ? gpus : avail;
+        if (n_dev_map) {
+            for (int g = 0; g < n_dev_map; g++)
+                if (dev_map[g] >= avail) { fprintf(stderr, "--devices: device %d does not exist (%d found)\n", dev_map[g], avail); return 1; }
+            n_workers = n_dev_map;
+        } else {
+            n_workers = gpus > 0 && gpus < avail ? gpus : avail;
+            for (int g = 0; g < n_workers && g < 64; g++) dev_map[g] = g;
+            if (n_workers > 64) n_workers = 64;
+        }
         if (n_workers > n_list) n_workers = n_list;
     }
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER; pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
@@ -318,13 +381,34 @@ int main(int argc, char **argv) {
     int *status = (int *)calloc((size_t)n_list, sizeof(int));
     emsar_em_stats *stats = (emsar_em_stats *)calloc((size_t)n_list, sizeof(emsar_em_stats));
     double *parse_s = (double *)calloc((size_t)n_list, sizeof(double));
+    double *model_s = (double *)calloc((size_t)n_list, sizeof(double)), *host_s = (double *)calloc((size_t)n_list, sizeof(double));
     worker_arg *wa = (worker_arg *)calloc((size_t)n_workers, sizeof(worker_arg));
     pthread_t *th = (pthread_t *)calloc((size_t)n_workers, sizeof(pthread_t));
+    if (!status || !stats || !parse_s || !model_s || !host_s || !wa || !th) { fprintf(stderr, "out of memory\n"); return 1; }
     t0 = now_s();
-    for (int g = 0; g < n_workers; g++) {
-        wa[g] = (worker_arg){&cfg, rsh, multisample ? g : device, n_workers, g, &mu, &cv, &next_model, &eumacut, status, stats, parse_s};
-        if (g > 0) pthread_create(&th[g], NULL, worker_main, &wa[g]);
+    /* Workers wait at a gate until their number is final: a thread that cannot be started must not leave the others
+     * waiting for samples nobody will take (the EUMAcut hand-over is in sample order). */
+    int go = 0, n_started = 1;
+    for (int g = 0; g < n_workers; g++)
+        wa[g] = (worker_arg){&cfg, rsh, multisample ? dev_map[g] : device, n_workers, g, &mu, &cv, &next_model, &eumacut, status, stats, parse_s,
+                             model_s, host_s, &go};
+    for (int g = 1; g < n_workers; g++) {
+        if (pthread_create(&th[g], NULL, worker_main, &wa[g]) != 0) { fprintf(stderr, "warning: worker %d could not be started, using %d\n", g, g); break; }
+        n_started++;
     }
+    /* every parallel host step of a worker gets its share of the cores: G workers x 16 reader threads each would
+     * oversubscribe the host (parse and inflate pools, emsar_host_threads) */
+    {
+        long nc = sysconf(_SC_NPROCESSORS_ONLN);
+        int share = (int)((nc < 1 ? 1 : nc) / n_started);
+        emsar_host_set_thread_budget(share < 1 ? 1 : share > 16 ? 16 : share);
+    }
+    pthread_mutex_lock(&mu);
+    n_workers = n_started;
+    for (int g = 0; g < n_workers; g++) wa[g].n_workers = n_workers;
+    go = 1;
+    pthread_cond_broadcast(&cv);
+    pthread_mutex_unlock(&mu);
     worker_main(&wa[0]);
     for (int g = 1; g < n_workers; g++) pthread_join(th[g], NULL);
     double wall = now_s() - t0;
@@ -335,9 +419,9 @@ int main(int argc, char **argv) {
         if (f) {
             fprintf(f, "{\"samples\": %d, \"gpus\": %d, \"wall_s\": %.6f, \"failed\": %d, \"per_sample\": [", n_list, n_workers, wall, bad);
             for (int i = 0; i < n_list; i++)
-                fprintf(f, "%s{\"status\": %d, \"parse_s\": %.6f, \"em_passes\": %d, \"converged\": %d, \"solve_ms\": %.4f, \"kernel_ms\": %.4f, \"loglik\": %.9g, \"bytes_per_pass\": %lld, "
+                fprintf(f, "%s{\"status\": %d, \"parse_s\": %.6f, \"model_s\": %.6f, \"host_s\": %.6f, \"em_passes\": %d, \"converged\": %d, \"solve_ms\": %.4f, \"kernel_ms\": %.4f, \"loglik\": %.9g, \"bytes_per_pass\": %lld, "
                            "\"sets_resident\": %d, \"sets_streamed\": %d, \"set_passes_max\": %d, \"set_passes_sum\": %lld, \"sets_build_ms\": %.4f, \"sets_kernel_ms\": %.4f}",
-                        i ? ", " : "", status[i], parse_s[i], stats[i].iters, stats[i].converged, stats[i].solve_ms, stats[i].kernel_ms, stats[i].loglik,
+                        i ? ", " : "", status[i], parse_s[i], model_s[i], host_s[i], stats[i].iters, stats[i].converged, stats[i].solve_ms, stats[i].kernel_ms, stats[i].loglik,
                         (long long)stats[i].bytes_per_pass, stats[i].sets_resident, stats[i].sets_streamed, stats[i].set_passes_max,
                         (long long)stats[i].set_passes_sum, stats[i].sets_build_ms, stats[i].sets_kernel_ms);
             fprintf(f, "]}\n");
@@ -346,6 +430,6 @@ int main(int argc, char **argv) {
     }
     emsar_rsh_free(rsh);
     for (int i = 0; i < n_list; i++) free(list[i]);
-    free(list); free(status); free(stats); free(parse_s); free(wa); free(th);
+    free(list); free(status); free(stats); free(parse_s); free(model_s); free(host_s); free(wa); free(th);
     return bad ? 1 : 0;
 }

@@ -56,6 +56,11 @@ int  emsar_rsh_read_cache(const char *src_path /* may be NULL: no staleness chec
 int32_t emsar_rsh_tid_of(const emsar_rsh *r, const char *name);                 /* -1 if unknown */
 int64_t emsar_rsh_row_of(const emsar_rsh *r, const int32_t *sorted_tids, int n); /* -1 if no such segment */
 
+/* host thread budget of the parallel readers (hostutil.c): min(online cores, 16) by default; a caller that runs several
+ * readers at once (emsar-hip -M: one worker per GPU) divides it; EMSAR_HOST_THREADS overrides both */
+void emsar_host_set_thread_budget(int n);   /* 0 = default */
+int  emsar_host_threads(void);
+
 /* parallel BGZF inflate (pbgzf.c): NULL from open = not a seekable BGZF file, use zlib's gzread instead.
  * read returns the bytes delivered (< n only at the end of the file), -1 on a damaged block. */
 struct emsar_pbgzf;

@@ -134,10 +134,7 @@ struct emsar_pbgzf *emsar_pbgzf_open(const char *path) {
     struct emsar_pbgzf *p = (struct emsar_pbgzf *)calloc(1, sizeof(*p));
     if (!p) { fclose(fp); return NULL; }
     p->fp = fp;
-    long nc = sysconf(_SC_NPROCESSORS_ONLN);
-    p->n_threads = nc > 16 ? 16 : nc < 1 ? 1 : (int)nc;
-    const char *e = getenv("EMSAR_HOST_THREADS");
-    if (e && atoi(e) > 0) p->n_threads = atoi(e) > 64 ? 64 : atoi(e);
+    p->n_threads = emsar_host_threads();
     for (int i = 0; i < 2; i++) {
         p->b[i].ubuf = (unsigned char *)malloc((size_t)PB_BLOCKS * PB_MAXBLK);
         if (!p->b[i].ubuf) { emsar_pbgzf_close(p); return NULL; }

@@ -372,10 +372,8 @@ int emsar_rsh_read(const char *path, emsar_rsh **out, char *err, size_t errlen) 
         int nt = 1;
         struct stat st;
         if (path && path[0] && strcmp(path, "-") != 0 && gzdirect(lr.f) && stat(path, &st) == 0 && S_ISREG(st.st_mode)) {
-            long nc = sysconf(_SC_NPROCESSORS_ONLN);
-            nt = nc > 16 ? 16 : nc < 1 ? 1 : (int)nc;
-            const char *e = getenv("EMSAR_HOST_THREADS");
-            if (e && atoi(e) > 0) nt = atoi(e) > 64 ? 64 : atoi(e);
+            nt = emsar_host_threads();
+            const char *e;
             int64_t min_bytes = (int64_t)16 << 20;
             if ((e = getenv("EMSAR_HOST_RANGE_BYTES")) && atoll(e) > 0) min_bytes = atoll(e);
             const int64_t by_size = ((int64_t)st.st_size - body) / min_bytes;

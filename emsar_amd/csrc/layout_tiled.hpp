@@ -125,6 +125,41 @@ inline void run_on_threads(int nt, F fn) {
     if (oom.load()) throw std::bad_alloc();
 }
 
+// Every range a kernel derives from a tile descriptor must lie inside the arrays it indexes -- k_pass_tiled has no bounds
+// checks, an out-of-range read is a GPU memory fault.  Checked on the host for every layout before it is uploaded
+// (build_tiled's last step) and again by check_tiled.  Per tile, as the kernels compute them (kernels_tiled.hpp):
+//   forward   int4 reads  [fwd_off/16 + 64*sum_{s'<s} k[s'], + 64*k[s])        k[s] >= 1 for every slice (load8_clamped reads n-1)
+//   backward  int4 reads  [bwd_off/16 + 64*sum m[s'], + 64*m[s])
+//   COO       dword reads [coo_off + sum coo_n[s'], + coo_n[s])
+//   far list  dword reads [far_off, far_off + far_n)
+//   rows      slots       [row_base, row_base + 768*n_slices)                   (weights, scatter values, slot_row)
+//   dictionary near_n + far_n <= kTileDict, tids lo .. lo + near_n - 1 and every far tid inside [0, n_tx)
+// 0 = fine, else a negative code naming the first violated rule.
+inline int check_tiled_extents(const TiledLayout &L) {
+    const uint64_t n_fwd = (uint64_t)L.fwd.size() / 4, n_bwd = (uint64_t)L.bwd.size() / 4;     // int4 units
+    for (const Tile &T : L.tiles) {
+        if (T.n_slices < 1 || T.n_slices > kTileSlices) return -21;
+        if ((int)T.near_n + (int)T.far_n > kTileDict || T.near_n < 1) return -22;
+        if (T.lo < 0 || (int64_t)T.lo + T.near_n > (int64_t)L.n_tx) return -23;
+        if ((uint64_t)T.far_off + T.far_n > (uint64_t)L.far_tid.size()) return -24;
+        for (uint32_t i = 0; i < T.far_n; i++) { const int32_t t = L.far_tid[(size_t)T.far_off + i]; if (t < 0 || t >= L.n_tx) return -24; }
+        if (T.fwd_off % 1024 || T.bwd_off % 1024 || T.row_base % kTileSliceRows) return -25;
+        uint64_t kf = 0, mb = 0, cn = 0;
+        for (int s = 0; s < kTileSlices; s++) {
+            if (s < (int)T.n_slices) { if (T.k[s] < 1 || T.k[s] > kMaxRowLen) return -26; }
+            else if (T.k[s] || T.m[s] || T.coo_n[s]) return -26;
+            kf += T.k[s]; mb += T.m[s]; cn += T.coo_n[s];
+        }
+        if (T.fwd_off / 16 + 64 * kf > n_fwd) return -27;
+        if (T.bwd_off / 16 + 64 * mb > n_bwd) return -28;
+        if ((uint64_t)T.coo_off + cn > (uint64_t)L.coo.size()) return -29;
+        if ((uint64_t)T.row_base + (uint64_t)T.n_slices * kTileSliceRows > (uint64_t)L.slot_row.size()) return -30;
+    }
+    if (L.left_ptr.size() != L.left_row.size() + 1 || (L.left_ptr.empty() ? 0 : L.left_ptr.back()) != (uint64_t)L.left_col.size()) return -31;
+    if (L.single_row.size() != L.single_tid.size()) return -32;
+    return 0;
+}
+
 // With merge_rows, rows with the same tid multiset (2..kMaxRowLen tids) are stored once and weighted by the sum of
 // their members' weights -- what the reference's update_ReadCounts does when it counts reads per segment
 // (emsar_functions.c:838-943).  Every quantity the library computes is a sum over rows of a function of the row's tid
@@ -526,6 +561,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 bwd_b[(size_t)g + 1] = bwd_b[(size_t)g] + F.bwd.size();
             }
             if (slot_b[(size_t)n_frag] >= ((size_t)1 << 32)) return -1;
+            if (nc_ >= ((size_t)1 << 32) || nfar_ >= ((size_t)1 << 32)) return -1;     // Tile::coo_off / far_off are 32-bit
             out.tiles.reserve(nt_); out.coo.reserve(nc_); out.far_tid.reserve(nfar_);
             out.slot_row.resize(slot_b[(size_t)n_frag]); out.fwd.resize(fwd_b[(size_t)n_frag]); out.bwd.resize(bwd_b[(size_t)n_frag]);
         }
@@ -564,11 +600,12 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     };
     std::stable_sort(out.tiles.begin(), out.tiles.end(), [&](const Tile &a, const Tile &b) { return work(a) > work(b); });
     if (dbg_t) fprintf(stderr, "build_tiled: total %.0f ms\n", t_ms(tp0, t_now()));
-    return 0;
+    return check_tiled_extents(out);       // O(tiles): no descriptor may point outside the arrays that are uploaded next
 }
 
 // Decode and compare with the input (host self-check, used by the CPU tests). 0 = identical.
 inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int32_t *col_idx) {
+    if (int rc = check_tiled_extents(L)) return rc;
     std::vector<uint8_t> seen((size_t)L.n_rows, 0);
     for (size_t i = 0; i < L.single_row.size(); i++) {
         uint32_t r = L.single_row[i];
