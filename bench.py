@@ -9,9 +9,9 @@ N>1 (torchrun, one rank per GPU): the -M multi-sample path -- every rank solves 
 of the same shape (different seed), no data-path collective; weak scaling.  The only torch.distributed use
 is the barrier and the max-over-ranks of the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel k_pass_windowed (+ the small k_update
-that shares the pass): algorithmic bytes per pass / mean device time per pass measured with
-HIP events on the library's own stream.  `cpu_baseline` times the CPU oracle's OpenMP EM pass on the same
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the TILED layout, k_pass_tiled /
+k_pass_tiled_multi<2> (+ the small k_update that shares the pass): algorithmic bytes per pass /
+mean device time per pass measured with HIP events on the library's own stream.  `cpu_baseline` times the CPU oracle's OpenMP EM pass on the same
 matrix on this box's host cores (rank 0, N=1 only).
 """
 import argparse
@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads and transcripts (debug only)")
-    ap.add_argument("--layout", default="auto", choices=["auto", "csr", "windowed", "tiled"])
+    ap.add_argument("--layout", default="auto", choices=["auto", "csr", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--xfam", type=float, default=None, help="experiment: override the config's share of cross-family reads")
     ap.add_argument("--merge-rows", action="store_true",
@@ -49,7 +49,7 @@ def main():
     import torch
     from emsar_amd import EmsarHip, synth
     from emsar_amd import dist as D
-    from emsar_amd.hip import LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_WINDOWED
+    from emsar_amd.hip import LAYOUT_AUTO, LAYOUT_CSR
 
     rank, world, local_rank = D.env_rank()
     if not torch.cuda.is_available():
@@ -74,7 +74,7 @@ def main():
     s = synth.make_matrix(**cfg)
     t_gen = time.time() - t0
     nnz = int(len(s["col_idx"]))
-    layout = {"auto": LAYOUT_AUTO, "csr": LAYOUT_CSR, "windowed": LAYOUT_WINDOWED, "tiled": 3}[args.layout]
+    layout = {"auto": LAYOUT_AUTO, "csr": LAYOUT_CSR, "tiled": 3}[args.layout]
     dev = EmsarHip(local_rank)
     t0 = time.time()
     dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], layout, merge_rows=args.merge_rows)
@@ -111,9 +111,7 @@ def main():
     out = None
     if rank == 0:
         per_pass_s = kernel_ms / 1e3 / args.steps
-        # unweighted TILED passes run two tiles per workgroup above 2048 tiles (emsar_hip.hip, launch_pass; EMSAR_HIP_TILED_MULTI 0/2 force)
-        knob = os.environ.get("EMSAR_HIP_TILED_MULTI", "1")
-        tiled_kernel = "k_pass_tiled_multi<2>" if knob == "2" or (knob == "1" and info["n_chunks"] > 2048) else "k_pass_tiled"
+        tiled_kernel = "k_pass_tiled"
         bytes_pass = info["bytes_per_pass"]
         achieved = bytes_pass / per_pass_s / 1e9
         out = {
@@ -122,14 +120,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d reads x %d transcripts, nnz %d (mean %.2f aln/read), read-level CSR, one sample per GPU"
                        % (args.config, s["n_reads"], s["n_tx"], nnz, nnz / s["n_reads"]),
-                       "layout": {1: "csr", 2: "windowed", 3: "tiled", 259: "tiled+merged-rows"}[info["layout"]], "parallelism": "1 sample per GPU x %d" % world},
+                       "layout": {1: "csr", 3: "tiled", 259: "tiled+merged-rows"}[info["layout"]], "parallelism": "1 sample per GPU x %d" % world},
             "read_alignments_per_s": world * nnz * args.steps / wall,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": {1: "k_pass_csr", 2: "k_pass_windowed", 3: tiled_kernel, 259: "k_pass_tiled"}[info["layout"]] + "+k_update",
+                         "kernel": {1: "k_pass_csr", 3: tiled_kernel, 259: "k_pass_tiled"}[info["layout"]] + "+k_update",
                          "algorithmic_bytes_per_pass": bytes_pass, "stored_bytes_per_pass": info["stored_bytes_per_pass"],
                          "device_ms_per_pass": per_pass_s * 1e3},
-            "layout_stats": {k: info[k] for k in ("n_chunks", "n_slices", "padded_entries", "far_entries", "window")},
+            "layout_stats": {k: info[k] for k in ("n_chunks", "n_groups", "n_slices", "padded_entries", "far_entries", "exported_entries", "window")},
             "setup_s": {"generate": round(t_gen, 2), "upload_and_layout": round(t_up, 2)},
             "mass_conserved": ok,
         }

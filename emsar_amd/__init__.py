@@ -4,6 +4,6 @@ The compute lives in libemsar_hip.so (hand-written HIP for gfx950, C ABI in incl
 package only loads it.  There is no CPU fallback: without the library or without a GPU every entry point
 raises.
 """
-from .hip import EmsarHip, EmsarHipError, load_library, layout_selfcheck, layout_selfcheck_tiled  # noqa: F401
+from .hip import EmsarHip, EmsarHipError, load_library, layout_selfcheck_tiled  # noqa: F401
 
-__all__ = ["EmsarHip", "EmsarHipError", "load_library", "layout_selfcheck", "layout_selfcheck_tiled"]
+__all__ = ["EmsarHip", "EmsarHipError", "load_library", "layout_selfcheck_tiled"]

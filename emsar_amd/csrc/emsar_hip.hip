@@ -9,9 +9,10 @@
 // One pass is HBM-bound integer streaming plus FP64 adds: ~2 flop per nonzero -- no MFMA.
 // This file: the context, the launch logic (launch_pass, enqueue_cycles, the set solver's driver) and the C ABI.
 // Kernels (one translation unit, included below):
-//   kernels_tiled.hpp     k_pass_tiled / k_pass_tiled_multi<2>   the hot ones: one workgroup per tile (or pair of tiles) of the
-//                         TILED layout, dictionary of theta/acc in LDS, 10-bit ids, per-slice transposed index
-//   kernels_windowed.hpp  k_pass_windowed, k_pass_csr            the WINDOWED layout and the caller's CSR (layouts 2 and 1)
+//   kernels_tiled.hpp     k_pass_tiled                           the hot one: one workgroup per chunk of the TILED layout, a
+//                         dictionary of theta/acc in LDS per group of slices, 10-bit ids, per-slice transposed index,
+//                         exported far entries
+//   kernels_csr.hpp       k_pass_csr                             the caller's CSR as it is (layout 1), leftover rows of TILED
 //   kernels_vector.hpp    k_update, k_update_p2/p3, k_sq_extrap_ll (SQUAREM extrapolation / acceptance on the device),
 //                         k_normalise, k_adj_euma, small reductions
 //   kernels_sets.hpp      k_solve_sets                           one workgroup solves one connected set out of LDS
@@ -34,7 +35,7 @@
 #include "internal.hpp"
 
 #include "kernels_common.hpp"
-#include "kernels_windowed.hpp"
+#include "kernels_csr.hpp"
 #include "kernels_tiled.hpp"
 #include "kernels_vector.hpp"
 #include "kernels_sets.hpp"
@@ -42,7 +43,6 @@
 // ==================================================================================================
 // context
 // ==================================================================================================
-constexpr int64_t kPairMinTiles = 2048;   // 256 CUs x 4 resident workgroups x 2 tiles
 
 struct emsar_hip_ctx {
     int device = 0;
@@ -60,20 +60,17 @@ struct emsar_hip_ctx {
     // CSR layout (device)
     void *d_row_ptr = nullptr;   // uint32 or uint64
     int32_t *d_col = nullptr;
-    // WINDOWED layout
-    emsar::WindowedLayout L;     // host copy keeps perm / slice_off / chunks (ent freed after upload)
-    Chunk *d_chunks = nullptr;
-    uint64_t *d_slice_off = nullptr;
-    int32_t *d_ent = nullptr;
-    int64_t padded_rows = 0;
     // TILED layout
     emsar::TiledLayout TL;       // host copy keeps slot_row / single_* / left_row (index arrays freed after upload)
-    Tile *d_tiles = nullptr;
+    emsar::ChunkDesc *d_chunks = nullptr; emsar::GroupDesc *d_groups = nullptr; emsar::SliceDesc *d_slices = nullptr;
     uint32_t *d_fwd = nullptr, *d_bwd = nullptr;
     uint32_t *d_coo = nullptr;
-    int32_t *d_far = nullptr;
+    int32_t *d_far = nullptr;    // explicit dictionary far lists
+    int32_t *d_far_blk = nullptr; double *d_far_w = nullptr; uint32_t *d_far_ptr = nullptr, *d_far_pos = nullptr;   // exported far entries
+    int64_t n_far_exported = 0;
+    int n_wg_slots = 1024;       // workgroups of the pass kernel the device holds at once (4 per CU)
     uint64_t *d_left_ptr = nullptr; int32_t *d_left_col = nullptr; int32_t *d_left_wgt = nullptr; double *d_left_val = nullptr;
-    int64_t n_left = 0, n_tiles = 0, n_slots = 0;
+    int64_t n_left = 0, n_chunks = 0, n_slots = 0;
     double *d_u = nullptr;       // folded single-tid rows: per-transcript weight sum
     // sample
     bool weighted = false;
@@ -88,15 +85,13 @@ struct emsar_hip_ctx {
     Scal *d_scal = nullptr;
     Scal *h_scal = nullptr;      // pinned
     int64_t bytes_formula = 0, bytes_stored = 0;
-    int64_t tl_fwd_slots = 0, tl_n_fslices = 0;
+    int64_t tl_fwd_slots = 0, tl_n_fslices = 0, tl_far_entries = 0;
     double count_floor = 0.0;    // stopping-rule floor in reads for the current solve (emsar_em_params.count_floor)
     double zero_cut = 0.0;       // emsar_em_params.zero_cut of the current solve
     bool use_graph = true;       // replay check_every cycles of the streaming solve from one hipGraph (EMSAR_HIP_GRAPH=0: launch each kernel)
     int64_t graph_launches = 0;  // of the last solve (debug: EMSAR_HIP_DEBUG)
     int update_grid = 256;       // workgroups of k_update (EMSAR_HIP_UPDATE_GRID)
     int sq_grid = 256;           // workgroups of the SQUAREM vector kernels (EMSAR_HIP_SQ_GRID)
-    int tiled_multi = 1;         // EMSAR_HIP_TILED_MULTI 1: two tiles per workgroup (k_pass_tiled_multi) above kPairMinTiles tiles, else one
-                                 // (k_pass_tiled); 2: always two; 0: always one
     const uint8_t *delta_mask = nullptr;   // d_kind while the streaming solve runs next to resident sets
     // set-resident solver (sets.hpp): host copy of the CSR and of the sample's row weights, built lazily by solve
     std::vector<uint64_t> h_row_ptr;
@@ -130,7 +125,7 @@ inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block
 
 // bytes one pass actually streams in the chosen layout: index arrays + row weights + the T-sized vectors
 inline int64_t stored_bytes(const emsar_hip_ctx *ctx) {
-    int64_t rows = ctx->layout == EMSAR_LAYOUT_WINDOWED ? ctx->padded_rows : ctx->layout == EMSAR_LAYOUT_TILED ? ctx->n_slots + ctx->n_left : ctx->n_rows;
+    int64_t rows = ctx->layout == EMSAR_LAYOUT_TILED ? ctx->n_slots + ctx->n_left : ctx->n_rows;
     return ctx->bytes_stored + (ctx->weighted ? 4 * rows : 0) + (ctx->layout == EMSAR_LAYOUT_TILED ? 40 : 32) * (int64_t)ctx->n_tx;
 }
 
@@ -149,50 +144,44 @@ void free_structure(emsar_hip_ctx *ctx) {
     free_sets(ctx);
     dfree(ctx->d_euma_t); dfree(ctx->d_wf); dfree(ctx->d_adj); ctx->d_euma_t = nullptr; ctx->d_wf = ctx->d_adj = nullptr; ctx->nfl = 0;
     std::vector<uint64_t>().swap(ctx->h_row_ptr); std::vector<int32_t>().swap(ctx->h_col); std::vector<int32_t>().swap(ctx->h_wgt);
-    dfree(ctx->d_row_ptr); dfree(ctx->d_col); dfree(ctx->d_chunks); dfree(ctx->d_slice_off); dfree(ctx->d_ent);
-    ctx->d_row_ptr = nullptr; ctx->d_col = nullptr; ctx->d_chunks = nullptr; ctx->d_slice_off = nullptr; ctx->d_ent = nullptr;
+    dfree(ctx->d_row_ptr); dfree(ctx->d_col);
+    ctx->d_row_ptr = nullptr; ctx->d_col = nullptr;
     dfree(ctx->d_wgt); dfree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
-    dfree(ctx->d_tiles); dfree(ctx->d_fwd); dfree(ctx->d_bwd); dfree(ctx->d_coo); dfree(ctx->d_far);
+    dfree(ctx->d_chunks); dfree(ctx->d_groups); dfree(ctx->d_slices); dfree(ctx->d_fwd); dfree(ctx->d_bwd); dfree(ctx->d_coo); dfree(ctx->d_far);
+    dfree(ctx->d_far_blk); dfree(ctx->d_far_w); dfree(ctx->d_far_ptr); dfree(ctx->d_far_pos);
+    ctx->d_far_blk = nullptr; ctx->d_far_w = nullptr; ctx->d_far_ptr = ctx->d_far_pos = nullptr; ctx->n_far_exported = 0;
     dfree(ctx->d_left_ptr); dfree(ctx->d_left_col); dfree(ctx->d_left_wgt); dfree(ctx->d_left_val); dfree(ctx->d_u);
-    ctx->d_tiles = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_coo = nullptr; ctx->d_far = nullptr;
+    ctx->d_chunks = nullptr; ctx->d_groups = nullptr; ctx->d_slices = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_coo = nullptr; ctx->d_far = nullptr;
     ctx->d_left_ptr = nullptr; ctx->d_left_col = nullptr; ctx->d_left_wgt = nullptr; ctx->d_left_val = nullptr; ctx->d_u = nullptr;
-    ctx->TL = emsar::TiledLayout(); ctx->n_left = ctx->n_tiles = ctx->n_slots = 0;
+    ctx->TL = emsar::TiledLayout(); ctx->n_left = ctx->n_chunks = ctx->n_slots = 0;
     dfree(ctx->d_den); dfree(ctx->d_acc); ctx->d_den = nullptr; ctx->d_acc = nullptr;
     for (auto &p : ctx->d_th) { dfree(p); p = nullptr; }
     for (auto &p : ctx->d_tmp) { dfree(p); p = nullptr; }
     dfree(ctx->d_itmp); ctx->d_itmp = nullptr;
-    ctx->L = emsar::WindowedLayout();
     ctx->have_structure = ctx->have_sample = false;
+}
+
+// the exported far entries of the TILED layout as the update kernels see them (null: none)
+inline FarList far_list(const emsar_hip_ctx *ctx) {
+    if (ctx->layout != EMSAR_LAYOUT_TILED || ctx->n_far_exported == 0) return FarList{nullptr, nullptr, nullptr};
+    return FarList{ctx->d_far_ptr, ctx->d_far_pos, ctx->d_far_w};
 }
 
 // one pass of the chosen layout.  mode: MODE_EM / MODE_EM_LL / MODE_SCATTER
 int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, double *ll_out, bool rows_only = false /* the folded rows' likelihood terms are added by the caller */) {
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
         const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
-        if (ctx->n_tiles > 0) {
-            dim3 grid((unsigned)ctx->n_tiles), block(kTiledThreads);
-#define LAUNCH_T(WT, MD)                                                                                          \
-    hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, ctx->d_tiles, ctx->d_fwd, ctx->d_bwd,   \
-                       ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out)
-#define LAUNCH_PN(WT, MD, NN)                                                                                     \
-    hipLaunchKernelGGL((k_pass_tiled_multi<WT, MD, NN>), dim3((unsigned)((ctx->n_tiles + NN - 1) / NN)), block, lds, ctx->stream, ctx->d_tiles,  \
-                       (int)ctx->n_tiles, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, theta, acc, ll_out)
-#define LAUNCH_P(WT, MD) LAUNCH_PN(WT, MD, 2)
+        if (ctx->n_chunks > 0) {
+            dim3 grid((unsigned)ctx->n_chunks), block(kTiledThreads);
+            const TiledArgs A{ctx->d_chunks, ctx->d_groups, ctx->d_slices, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_far_blk, ctx->d_far_w,
+                              ctx->d_wgt, ctx->d_rowval};
+#define LAUNCH_T(WT, MD) hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, A, theta, acc, ll_out)
             if (mode == MODE_SCATTER) LAUNCH_T(false, MODE_SCATTER);
-            else if (!ctx->weighted && (ctx->tiled_multi >= 2 || (ctx->tiled_multi == 1 && ctx->n_tiles > kPairMinTiles))) {
-                // two tiles per workgroup, software-pipelined: +3 % on config 3.  Unweighted rows only: with the row
-                // weights in registers as well the two-tile body does not fit 128 VGPRs (0.218 vs 0.179 ms measured).
-                // Only when the tiles outnumber the chip's workgroup slots: below that a pass is one workgroup's latency, and
-                // a pair takes twice as long as a tile (40 k reads: 47 -> 26 us per pass with one tile per workgroup)
-                if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM);
-            }
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
             else { if (mode == MODE_EM_LL) LAUNCH_T(false, MODE_EM_LL); else LAUNCH_T(false, MODE_EM); }
-#undef LAUNCH_P
-#undef LAUNCH_PN
 #undef LAUNCH_T
         }
-        if (ctx->n_left > 0) {   // rows too long for a tile: generic CSR kernel on the leftover
+        if (ctx->n_left > 0) {   // rows too long for a slice: generic CSR kernel on the leftover
             dim3 grid((unsigned)std::min<int64_t>((ctx->n_left + 255) / 256, 8192)), block(256);
 #define LAUNCH_L(WT, MD)                                                                                          \
     hipLaunchKernelGGL((k_pass_csr<uint64_t, WT, MD>), grid, block, 0, ctx->stream, ctx->n_left, ctx->d_left_ptr,     \
@@ -202,38 +191,26 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
             else { if (mode == MODE_EM_LL) LAUNCH_L(false, MODE_EM_LL); else LAUNCH_L(false, MODE_EM); }
 #undef LAUNCH_L
         }
+        if (mode == MODE_SCATTER && ctx->n_far_exported > 0)      // the scattered value of the rows with an exported entry, to that entry's transcript
+            hipLaunchKernelGGL(k_far_add, dim3(grid_for(ctx->n_tx, 256)), dim3(256), 0, ctx->stream, ctx->n_tx, far_list(ctx), acc);
         if (mode == MODE_EM_LL && !rows_only)
             hipLaunchKernelGGL(k_single_ll, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx,
                                ctx->d_u, theta, ll_out);
         HIPCHK(hipGetLastError());
         return EMSAR_HIP_OK;
     }
-    if (ctx->layout == EMSAR_LAYOUT_WINDOWED) {
-        const int W = ctx->L.window;
-        const size_t lds = (size_t)W * 2 * sizeof(double);
-        dim3 grid((unsigned)ctx->L.chunks.size()), block(kPassThreads);
-        if (grid.x == 0) return EMSAR_HIP_OK;
-#define LAUNCH_W(WT, MD)                                                                                          \
-    hipLaunchKernelGGL((k_pass_windowed<kPassThreads, WT, MD>), grid, block, lds, ctx->stream, ctx->d_chunks,      \
-                       ctx->d_slice_off, ctx->d_ent, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out, W)
-        if (mode == MODE_SCATTER) LAUNCH_W(false, MODE_SCATTER);
-        else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_W(true, MODE_EM_LL); else LAUNCH_W(true, MODE_EM); }
-        else { if (mode == MODE_EM_LL) LAUNCH_W(false, MODE_EM_LL); else LAUNCH_W(false, MODE_EM); }
-#undef LAUNCH_W
-    } else {
-        if (ctx->n_rows == 0) return EMSAR_HIP_OK;
-        int64_t blocks = (ctx->n_rows + 255) / 256;
-        dim3 grid((unsigned)std::min<int64_t>(blocks, 256 * 32)), block(256);
+    if (ctx->n_rows == 0) return EMSAR_HIP_OK;
+    int64_t blocks = (ctx->n_rows + 255) / 256;
+    dim3 grid((unsigned)std::min<int64_t>(blocks, 256 * 32)), block(256);
 #define LAUNCH_C(PT, WT, MD)                                                                                     \
     hipLaunchKernelGGL((k_pass_csr<PT, WT, MD>), grid, block, 0, ctx->stream, ctx->n_rows, (const PT *)ctx->d_row_ptr, \
                        ctx->d_col, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out)
 #define LAUNCH_CP(WT, MD) do { if (ctx->ptr64) LAUNCH_C(uint64_t, WT, MD); else LAUNCH_C(uint32_t, WT, MD); } while (0)
-        if (mode == MODE_SCATTER) LAUNCH_CP(false, MODE_SCATTER);
-        else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_CP(true, MODE_EM_LL); else LAUNCH_CP(true, MODE_EM); }
-        else { if (mode == MODE_EM_LL) LAUNCH_CP(false, MODE_EM_LL); else LAUNCH_CP(false, MODE_EM); }
+    if (mode == MODE_SCATTER) LAUNCH_CP(false, MODE_SCATTER);
+    else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_CP(true, MODE_EM_LL); else LAUNCH_CP(true, MODE_EM); }
+    else { if (mode == MODE_EM_LL) LAUNCH_CP(false, MODE_EM_LL); else LAUNCH_CP(false, MODE_EM); }
 #undef LAUNCH_CP
 #undef LAUNCH_C
-    }
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
 }
@@ -244,7 +221,7 @@ int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_l
     if (rc) return rc;
     hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), ctx->update_grid)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
                        ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->zero_cut, ctx->d_scal,
-                       ctx->delta_mask, to_delta1);
+                       ctx->delta_mask, to_delta1, far_list(ctx));
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
 }
@@ -268,10 +245,10 @@ int enqueue_cycles(emsar_hip_ctx *ctx, const emsar_em_params &p, double abs_step
         const dim3 gv((unsigned)std::min(g, ctx->sq_grid)), bv(256);
         if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor, 1))) return rc;
         if ((rc = launch_pass(ctx, MODE_EM_LL, th[1], ctx->d_acc, &ctx->d_scal->ll[1].v, true))) return rc;
-        hipLaunchKernelGGL(k_update_p2, gv, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal);
+        hipLaunchKernelGGL(k_update_p2, gv, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal, far_list(ctx));
         hipLaunchKernelGGL(k_sq_extrap_ll, gv, bv, 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, u, th[3], ctx->d_scal);
         if ((rc = launch_pass(ctx, MODE_EM_LL, th[3], ctx->d_acc, &ctx->d_scal->ll[2].v, true))) return rc;
-        hipLaunchKernelGGL(k_update_p3, gv, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal);
+        hipLaunchKernelGGL(k_update_p3, gv, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal, far_list(ctx));
         HIPCHK(hipGetLastError());
     }
     return EMSAR_HIP_OK;
@@ -311,22 +288,15 @@ int scatter_rows(emsar_hip_ctx *ctx, const double *val_host, double *d_out) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
             return EMSAR_HIP_OK;
         }
-        std::vector<double> tmp;
         const double *src = val_host;
         size_t n = (size_t)ctx->n_rows;
-        if (ctx->layout == EMSAR_LAYOUT_WINDOWED) {
-            n = (size_t)ctx->padded_rows;
-            tmp.assign(n, 0.0);
-            for (int64_t i = 0; i < ctx->L.n_sorted_rows; i++) tmp[(size_t)i] = val_host[ctx->L.perm[(size_t)i]];
-            src = tmp.data();
-        }
         if (n == 0) return EMSAR_HIP_OK;
         if (!ctx->d_rowval) HIPCHK(hipMalloc(&ctx->d_rowval, std::max<size_t>(n, 1) * sizeof(double)));
         HIPCHK(hipMemcpyAsync(ctx->d_rowval, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)ctx->n_tx * sizeof(double), ctx->stream));
         int rc = launch_pass(ctx, MODE_SCATTER, nullptr, d_out, nullptr);
         if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(ctx->stream));  // tmp must outlive the copy
+        HIPCHK(hipStreamSynchronize(ctx->stream));
         return EMSAR_HIP_OK;
     } catch (const std::bad_alloc &) { ctx->err = "out of host memory"; return EMSAR_HIP_ERR_OOM; }
 }
@@ -481,7 +451,7 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
     if (!ctx) return EMSAR_HIP_ERR_ARG;
     const bool merge_rows = (layout & EMSAR_LAYOUT_FLAG_MERGE_ROWS) != 0;
     layout &= ~EMSAR_LAYOUT_FLAG_MERGE_ROWS;
-    if (layout != EMSAR_LAYOUT_AUTO && layout != EMSAR_LAYOUT_CSR && layout != EMSAR_LAYOUT_WINDOWED && layout != EMSAR_LAYOUT_TILED) return EMSAR_HIP_ERR_ARG;
+    if (layout != EMSAR_LAYOUT_AUTO && layout != EMSAR_LAYOUT_CSR && layout != EMSAR_LAYOUT_TILED) return EMSAR_HIP_ERR_ARG;
     if (merge_rows && layout != EMSAR_LAYOUT_AUTO && layout != EMSAR_LAYOUT_TILED) return EMSAR_HIP_ERR_ARG;
     if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
@@ -492,7 +462,7 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
     if (const char *e = getenv("EMSAR_HIP_FORCE_PTR64")) { if (atoi(e) != 0) ctx->ptr64 = true; }   // test hook: the 64-bit row_ptr kernels on small inputs
     if (layout == EMSAR_LAYOUT_AUTO) {
         layout = (n_rows < ((int64_t)1 << 32)) ? EMSAR_LAYOUT_TILED : EMSAR_LAYOUT_CSR;
-        if (const char *e = getenv("EMSAR_HIP_LAYOUT")) { int v = atoi(e); if (v >= 1 && v <= 3 && (v == 1 || n_rows < ((int64_t)1 << 32))) layout = v; }
+        if (const char *e = getenv("EMSAR_HIP_LAYOUT")) { int v = atoi(e); if ((v == 1 || v == 3) && (v == 1 || n_rows < ((int64_t)1 << 32))) layout = v; }
         if (merge_rows && layout != EMSAR_LAYOUT_TILED) return EMSAR_HIP_ERR_ARG;
     }
     ctx->layout = layout;
@@ -513,60 +483,53 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
     try {
         if (layout == EMSAR_LAYOUT_TILED) {
             auto &L = ctx->TL;
-            if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows) != 0) return EMSAR_HIP_ERR_ARG;
+            {   // as many chunks as the device holds workgroups of the pass kernel: 4 per CU (LDS and registers both allow 4)
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_wg_slots = 4 * prop.multiProcessorCount;
+            }
+            const int brc = emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows, ctx->n_wg_slots);
+            if (brc != 0) { ctx->err = "TILED layout builder: code " + std::to_string(brc); return EMSAR_HIP_ERR_ARG; }
             if (dbg) fprintf(stderr, "upload_structure: layout built after %.0f ms\n", since(tu0));
-            ctx->n_tiles = (int64_t)L.tiles.size(); ctx->n_slots = L.n_slots(); ctx->n_left = (int64_t)L.left_row.size();
+            ctx->n_chunks = (int64_t)L.chunks.size(); ctx->n_slots = L.n_slots(); ctx->n_left = (int64_t)L.left_row.size();
+            ctx->n_far_exported = (int64_t)L.far_pos.size();
             auto up = [&](void **dp, const void *src, size_t bytes) -> hipError_t {
                 hipError_t e = hipMalloc(dp, std::max<size_t>(bytes, 16));
                 if (e == hipSuccess && bytes) e = hipMemcpy(*dp, src, bytes, hipMemcpyHostToDevice);
                 return e;
             };
-            HIPCHK(up((void **)&ctx->d_tiles, L.tiles.data(), L.tiles.size() * sizeof(Tile)));
+            HIPCHK(up((void **)&ctx->d_chunks, L.chunks.data(), L.chunks.size() * sizeof(emsar::ChunkDesc)));
+            HIPCHK(up((void **)&ctx->d_groups, L.groups.data(), L.groups.size() * sizeof(emsar::GroupDesc)));
+            HIPCHK(up((void **)&ctx->d_slices, L.slices.data(), L.slices.size() * sizeof(emsar::SliceDesc)));
             HIPCHK(up((void **)&ctx->d_fwd, L.fwd.data(), L.fwd.size() * 4));
             HIPCHK(up((void **)&ctx->d_bwd, L.bwd.data(), L.bwd.size() * 4));
             HIPCHK(up((void **)&ctx->d_coo, L.coo.data(), L.coo.size() * 4));
             HIPCHK(up((void **)&ctx->d_far, L.far_tid.data(), L.far_tid.size() * 4));
+            HIPCHK(up((void **)&ctx->d_far_blk, L.far_blk_tid.data(), L.far_blk_tid.size() * 4));
+            HIPCHK(up((void **)&ctx->d_far_ptr, L.far_ptr.data(), L.far_ptr.size() * 4));
+            HIPCHK(up((void **)&ctx->d_far_pos, L.far_pos.data(), L.far_pos.size() * 4));
+            HIPCHK(hipMalloc(&ctx->d_far_w, std::max<size_t>(L.far_blk_tid.size(), 2) * 8));
+            HIPCHK(hipMemset(ctx->d_far_w, 0, std::max<size_t>(L.far_blk_tid.size(), 2) * 8));
             HIPCHK(up((void **)&ctx->d_left_ptr, L.left_ptr.data(), L.left_ptr.size() * 8));
             HIPCHK(up((void **)&ctx->d_left_col, L.left_col.data(), L.left_col.size() * 4));
             HIPCHK(hipMalloc(&ctx->d_u, T * 8));
             HIPCHK(hipMemset(ctx->d_u, 0, T * 8));
+            // what one pass streams: both indices, the COO and far lists, the descriptors, the far blocks (tids read, weights
+            // written by the pass and read back by the update kernel through far_pos)
             ctx->bytes_stored = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 + (int64_t)L.far_tid.size() * 4 +
-                                (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4 + (int64_t)L.left_ptr.size() * 8;
-            ctx->tl_fwd_slots = L.padded_slots; ctx->tl_n_fslices = L.n_fslices;
+                                (int64_t)L.slices.size() * 32 + (int64_t)L.groups.size() * 32 + (int64_t)L.chunks.size() * 8 +
+                                (int64_t)L.far_blk_tid.size() * (4 + 8) + (int64_t)L.far_pos.size() * (4 + 8) + (L.far_pos.empty() ? 0 : (int64_t)L.far_ptr.size() * 4) +
+                                (int64_t)L.left_col.size() * 4 + (int64_t)L.left_ptr.size() * 8;
+            ctx->tl_fwd_slots = L.padded_slots; ctx->tl_n_fslices = (int64_t)L.slices.size();
+            ctx->tl_far_entries = L.far_entries + L.exported_entries;
             emsar::u32_vec().swap(L.fwd); emsar::u32_vec().swap(L.bwd); std::vector<uint32_t>().swap(L.coo);
-            std::vector<int32_t>().swap(L.left_col);
+            std::vector<int32_t>().swap(L.left_col); std::vector<int32_t>().swap(L.far_blk_tid);
+            std::vector<uint32_t>().swap(L.far_pos); std::vector<uint32_t>().swap(L.far_ptr);
             const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
 #define SETLDS_T(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             SETLDS_T(false, MODE_EM); SETLDS_T(false, MODE_EM_LL); SETLDS_T(true, MODE_EM); SETLDS_T(true, MODE_EM_LL); SETLDS_T(false, MODE_SCATTER);
 #undef SETLDS_T
-#define SETLDS_P(WT, MD, NN) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_multi<WT, MD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-            SETLDS_P(false, MODE_EM, 2); SETLDS_P(false, MODE_EM_LL, 2);
-#undef SETLDS_P
-            { const char *pe = getenv("EMSAR_HIP_TILED_MULTI"); ctx->tiled_multi = pe ? atoi(pe) : 1; }
             { const char *pe = getenv("EMSAR_HIP_UPDATE_GRID"); if (pe && atoi(pe) >= 1) ctx->update_grid = atoi(pe); }
             { const char *pe = getenv("EMSAR_HIP_SQ_GRID"); if (pe && atoi(pe) >= 1) ctx->sq_grid = atoi(pe); }
-        } else if (layout == EMSAR_LAYOUT_WINDOWED) {
-            const char *wenv = getenv("EMSAR_HIP_WINDOW");
-            int window = wenv ? atoi(wenv) : kDefaultWindow;
-            if (window < emsar::kMinBlockTids || window > 8192) window = kDefaultWindow;
-            const char *cenv = getenv("EMSAR_HIP_CHUNK_ENTRIES");
-            int64_t chunk_entries = cenv ? atoll(cenv) : kChunkEntries;
-            if (chunk_entries < 1024) chunk_entries = kChunkEntries;
-            if (emsar::build_windowed(n_rows, n_tx, row_ptr, col_idx, window, chunk_entries, ctx->L) != 0) return EMSAR_HIP_ERR_ARG;
-            auto &L = ctx->L;
-            ctx->padded_rows = L.n_slices() * emsar::kSliceRows;
-            HIPCHK(hipMalloc(&ctx->d_chunks, std::max<size_t>(L.chunks.size(), 1) * sizeof(Chunk)));
-            HIPCHK(hipMalloc(&ctx->d_slice_off, L.slice_off.size() * sizeof(uint64_t)));
-            HIPCHK(hipMalloc(&ctx->d_ent, std::max<size_t>(L.ent.size(), 1) * sizeof(int32_t)));
-            HIPCHK(hipMemcpy(ctx->d_chunks, L.chunks.data(), L.chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(ctx->d_slice_off, L.slice_off.data(), L.slice_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(ctx->d_ent, L.ent.data(), L.ent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            ctx->bytes_stored = (int64_t)L.ent.size() * 4 + (int64_t)L.slice_off.size() * 8 + (int64_t)L.chunks.size() * 16;
-            std::vector<int32_t>().swap(L.ent);  // the device copy is the only one needed from here on
-            const size_t lds = (size_t)window * 2 * sizeof(double);
-#define SETLDS(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_windowed<kPassThreads, WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-            SETLDS(false, MODE_EM); SETLDS(false, MODE_EM_LL); SETLDS(true, MODE_EM); SETLDS(true, MODE_EM_LL); SETLDS(false, MODE_SCATTER);
-#undef SETLDS
         } else {
             if (ctx->ptr64) {
                 HIPCHK(hipMalloc(&ctx->d_row_ptr, ((size_t)n_rows + 1) * 8));
@@ -674,15 +637,11 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
             HIPCHK(hipMemcpy(ctx->d_left_wgt, wl.data(), wl.size() * 4, hipMemcpyHostToDevice));
         }
     } else if (ctx->weighted) {
-        const bool win = ctx->layout == EMSAR_LAYOUT_WINDOWED;
-        size_t n = win ? (size_t)ctx->padded_rows : (size_t)n_rows;
-        std::vector<int32_t> w(std::max<size_t>(n, 1), 0);
-        int64_t cnt = win ? ctx->L.n_sorted_rows : n_rows;
-        for (int64_t i = 0; i < cnt; i++) {
-            int64_t r = win ? (int64_t)ctx->L.perm[(size_t)i] : i;
+        std::vector<int32_t> w(std::max<size_t>((size_t)n_rows, 1), 0);
+        for (int64_t r = 0; r < n_rows; r++) {
             int32_t x = row_weight ? row_weight[r] : 1;
             if (row_E && row_E[r] == 0.0) x = 0;
-            w[(size_t)i] = x;
+            w[(size_t)r] = x;
             if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[r]);
         }
         HIPCHK(hipMalloc(&ctx->d_wgt, w.size() * 4));
@@ -762,7 +721,7 @@ int emsar_hip_solve(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_
     return rc;
 }
 static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpkm_out, emsar_em_stats *stats) {
-    emsar_em_params p = pp ? *pp : emsar_em_params{0, 1, 0, 0, 0, 0, 0, 0, 0};
+    emsar_em_params p = pp ? *pp : emsar_em_params{0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (p.max_iter <= 0) p.max_iter = 100000;
     if (p.tol <= 0) p.tol = 1e-10;
     if (p.abs_floor <= 0) p.abs_floor = 1e-6;
@@ -827,7 +786,8 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
     ctx->delta_mask = nullptr;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (use_sets) {
-        SetSolveParams P{p.tol, p.abs_floor, p.count_floor, p.zero_cut > 0.0 ? p.zero_cut : 0.0, p.abs_step > 0.0 ? p.abs_step : 0.0, p.max_iter, p.accel};
+        SetSolveParams P{p.tol, p.abs_floor, p.count_floor, p.zero_cut > 0.0 ? p.zero_cut : 0.0, p.abs_step > 0.0 ? p.abs_step : 0.0, p.max_iter, p.accel,
+                         p.newton_after == 0 ? 60 : p.newton_after};
         if ((rc = solve_resident_sets(ctx, P, th[0]))) return rc;
         if (ctx->n_sstat > 0)
             HIPCHK(hipMemcpyAsync(ctx->h_sstat, ctx->d_sstat, (size_t)ctx->n_sstat * sizeof(SetStat), hipMemcpyDeviceToHost, ctx->stream));
@@ -963,68 +923,12 @@ int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *o) {
     o->n_rows = ctx->n_rows; o->nnz = ctx->nnz; o->n_tx = ctx->n_tx; o->device_id = ctx->device;
     o->layout = ctx->layout | ((ctx->layout == EMSAR_LAYOUT_TILED && ctx->TL.merged) ? EMSAR_LAYOUT_FLAG_MERGE_ROWS : 0);
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
-        o->n_chunks = ctx->n_tiles; o->n_slices = ctx->tl_n_fslices; o->padded_entries = ctx->tl_fwd_slots;
-        o->far_entries = ctx->TL.far_entries; o->window = emsar::kTileDict;
-    }
-    if (ctx->layout == EMSAR_LAYOUT_WINDOWED) {
-        o->n_chunks = (int64_t)ctx->L.chunks.size();
-        o->n_slices = ctx->L.n_slices();
-        o->padded_entries = (int64_t)ctx->L.slice_off.back();
-        o->far_entries = ctx->L.far_entries;
-        o->window = ctx->L.window;
+        o->n_chunks = ctx->n_chunks; o->n_slices = ctx->tl_n_fslices; o->padded_entries = ctx->tl_fwd_slots;
+        o->far_entries = ctx->tl_far_entries; o->window = emsar::kTileDict;
+        o->n_groups = (int64_t)ctx->TL.groups.size(); o->exported_entries = ctx->n_far_exported;
     }
     o->bytes_per_pass = ctx->bytes_formula;
     o->stored_bytes_per_pass = stored_bytes(ctx);
-    return EMSAR_HIP_OK;
-}
-
-// Host-only self check of the WINDOWED layout builder (no HIP call: usable on a machine without a GPU).
-// Builds the layout for the given CSR, decodes it again and compares; fills *info_out (may be NULL).
-int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
-                               int32_t window, int64_t chunk_entries, emsar_hip_info *info_out) {
-    try {
-        if (emsar::validate_csr(n_rows, n_tx, row_ptr, col_idx) != 0) return EMSAR_HIP_ERR_ARG;
-        emsar::WindowedLayout L;
-        if (window <= 0) window = kDefaultWindow;
-        if (chunk_entries <= 0) chunk_entries = kChunkEntries;
-        if (emsar::build_windowed(n_rows, n_tx, row_ptr, col_idx, window, chunk_entries, L) != 0) return EMSAR_HIP_ERR_ARG;
-        int rc = emsar::check_windowed(L, row_ptr, col_idx);
-        if (info_out) {
-            memset(info_out, 0, sizeof(*info_out));
-            info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx; info_out->layout = EMSAR_LAYOUT_WINDOWED;
-            info_out->n_chunks = (int64_t)L.chunks.size(); info_out->n_slices = L.n_slices();
-            info_out->padded_entries = (int64_t)L.slice_off.back(); info_out->far_entries = L.far_entries; info_out->window = window;
-        }
-        return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
-    } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }     // nothing may leave the C ABI as an exception
-}
-
-// Diagnostic only (not declared in the public header): one stamped pass of the TILED kernel on the current theta.
-// out[0..6] = mean cycles per wave spent in: loads issued + dictionary, barrier, E-step, barrier, M-step, barrier, flush;
-// out[7] = tiles.  The result vector theta is left untouched (acc is cleared again).
-int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
-    if (!ctx || !out || ctx->layout != EMSAR_LAYOUT_TILED || !ctx->have_sample || ctx->weighted || ctx->n_tiles == 0) return EMSAR_HIP_ERR_STATE;
-    HIPCHK(hipSetDevice(ctx->device));
-    unsigned long long *d = nullptr;
-    const size_t nw = (size_t)ctx->n_tiles * (kTiledThreads / 64), bytes = nw * 8 * sizeof(unsigned long long);
-    HIPCHK(hipMalloc(&d, bytes));
-    HIPCHK(hipMemsetAsync(d, 0, bytes, ctx->stream));
-    const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
-    HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<false, MODE_EM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_pass_tiled<false, MODE_EM, true>), dim3((unsigned)ctx->n_tiles), dim3(kTiledThreads), lds, ctx->stream, ctx->d_tiles,
-                       ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].v, d);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
-    std::vector<unsigned long long> h(nw * 8);
-    HIPCHK(hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    dfree(d);
-    for (int i = 0; i < 7; i++) {
-        double sum = 0;
-        for (size_t w = 0; w < nw; w++) sum += (double)h[w * 8 + (size_t)i];
-        out[i] = sum / (double)nw;   // mean cycles per wave
-    }
-    out[7] = (double)ctx->n_tiles;
     return EMSAR_HIP_OK;
 }
 
@@ -1039,11 +943,13 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
             memset(info_out, 0, sizeof(*info_out));
             info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx;
             info_out->layout = EMSAR_LAYOUT_TILED | (L.merged ? EMSAR_LAYOUT_FLAG_MERGE_ROWS : 0);
-            info_out->n_chunks = (int64_t)L.tiles.size();
-            info_out->n_slices = L.n_fslices;
-            info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries; info_out->window = emsar::kTileDict;
+            info_out->n_chunks = (int64_t)L.chunks.size();
+            info_out->n_slices = (int64_t)L.slices.size();
+            info_out->n_groups = (int64_t)L.groups.size(); info_out->exported_entries = L.exported_entries;
+            info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries + L.exported_entries; info_out->window = emsar::kTileDict;
             info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 +
-                                              (int64_t)L.far_tid.size() * 4 + (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4;
+                                              (int64_t)L.far_tid.size() * 4 + (int64_t)L.slices.size() * 32 + (int64_t)L.groups.size() * 32 +
+                                              (int64_t)L.far_blk_tid.size() * 12 + (int64_t)L.far_pos.size() * 12 + (int64_t)L.left_col.size() * 4;
             info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
         }
         return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;

@@ -4,11 +4,6 @@
 
 namespace {
 
-using emsar::Chunk;
-using emsar::Tile;
-constexpr int kPassThreads = 512;     // 8 waves per workgroup
-constexpr int kDefaultWindow = 4096;  // 2 x 32 KiB of LDS per workgroup -> 2 workgroups per CU
-constexpr int64_t kChunkEntries = 65536;
 
 // ------------------------------------------------------------------------------------------------
 // device scalars of one solve (lives in HBM, polled by the host every check_every cycles)

@@ -15,7 +15,7 @@ namespace {
 // step as the streaming solve below, so both reach the same fixed point.
 // ------------------------------------------------------------------------------------------------
 struct SetStat { int32_t passes, converged; double delta; };
-struct SetSolveParams { double tol, abs_floor, count_floor, zero_cut, abs_step; int32_t max_iter, accel; };
+struct SetSolveParams { double tol, abs_floor, count_floor, zero_cut, abs_step; int32_t max_iter, accel, newton_after /* < 0: off */; };
 
 // Wave-wide reductions on the DPP path (row shifts inside rows of 16 lanes, then row broadcasts; the total lands in lane
 // 63 and is read back as a scalar): ~6 cross-lane moves per value instead of the twelve ds_bpermute round trips of a
@@ -111,6 +111,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 struct SetLds {
     double *den, *u, *w, *rw, *red;
+    double *z, *hp, *mi, *hrow;      // Newton step: direction, Hessian-vector product / trial point, preconditioner + masks, R/S^2 per row
     const uint16_t *rp, *ent, *cp, *crow;
     int nt, nr;
 };
@@ -152,6 +153,148 @@ __device__ __forceinline__ double set_em_update(double x, double a, double u, do
     return dn > 0.0 ? (x > 0.0 ? (x * a + u) * fast_rcp(dn) : 0.0) : 0.0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The safeguarded second-order step.  The set objective F(theta) = sum_c R_c log S_c + sum_t u_t log theta_t - sum_t theta_t den_t
+// (Fp, emsar_functions.c:2946-2975, with E folded into den) is concave; the EM -- with or without SQUAREM -- creeps along
+// nearly flat directions (10^4 .. 10^5 passes for a badly conditioned family of a few dozen isoforms) and decays like 1/k
+// towards a boundary optimum theta_t = 0 with zero gradient.  Once a set has used newton_after passes without converging,
+// every SQUAREM cycle is followed by one projected Newton step (Bertsekas 1982):
+//   * components that are tiny (theta_t den_t < 1e-6 reads), carry no single-transcript reads and have a negative gradient are
+//     BOUND: they go to exactly 0 (an EM fixed point; the stopping rule re-opens one whose gradient at 0 turns positive);
+//   * for the FREE components the direction solves (-H) d = g by preconditioned conjugate gradients, matrix-free:
+//     (-H) v = A^T diag(R/S^2) A v + diag(u/theta^2) v is one row sweep and one column sweep over the set's CSR / CSC -- the
+//     cost of an EM pass, and counted as one; Jacobi preconditioner; at most n_free iterations (exact in exact arithmetic);
+//   * the step is projected onto theta >= 0 and ACCEPTED ONLY IF F DOES NOT FALL (step 1, 1/4, 1/16, 1/64); otherwise the point is
+//     left alone and the next eight cycles are plain SQUAREM.
+// Convergence is still declared by the plain EM step's relative change (same rule, same tol as without the Newton steps), so
+// the fixed point reached is the EM's.  tools/newton_proto.py is the numpy prototype of exactly this procedure.
+// ------------------------------------------------------------------------------------------------
+template <int THREADS>
+__device__ __forceinline__ double set_row_dot(const SetLds &L, const double *v, int j) {
+    double S = 0.0;
+    const int b = L.rp[j], e = L.rp[j + 1];
+    for (int k = b; k < e; k += 4) {
+        const int l = e - 1;
+        const int i0 = L.ent[k], i1 = L.ent[k + 1 < e ? k + 1 : l], i2 = L.ent[k + 2 < e ? k + 2 : l], i3 = L.ent[k + 3 < e ? k + 3 : l];
+        const double v0 = v[i0], v1 = v[i1], v2 = v[i2], v3 = v[i3];
+        S += (v0 + (k + 1 < e ? v1 : 0.0)) + ((k + 2 < e ? v2 : 0.0) + (k + 3 < e ? v3 : 0.0));
+    }
+    return S;
+}
+__device__ __forceinline__ double set_col_sum(const SetLds &L, const double *rowv, int i) {
+    double a = 0.0;
+    const int b = L.cp[i], e = L.cp[i + 1];
+    for (int k = b; k < e; k++) a += rowv[L.crow[k]];
+    return a;
+}
+// x: current point (left untouched unless the step is accepted), r / p: two transcript vectors of scratch.
+// Returns true if x was replaced; adds its pass-equivalents to `passes`.
+template <int THREADS>
+__device__ __forceinline__ bool set_newton_step(const SetLds &L, double *x, double *r, double *p, int &passes) {
+    const int nt = L.nt, nr = L.nr;
+    constexpr double kBoundReads = 1e-6;
+    // ---- E-step quantities at x: w = R/S, h = R/S^2, F(x) ----
+    double s3[3] = {0.0, 0.0, 0.0};        // sum R log S (+ u log x), sum x den, r.q
+    for (int j = threadIdx.x; j < nr; j += THREADS) {
+        const double S = set_row_dot<THREADS>(L, x, j), rw = L.rw[j];
+        const bool live = S > 0.0;
+        const double inv = live ? fast_rcp(S) : 0.0;
+        L.w[j] = rw * inv; L.hrow[j] = rw * inv * inv;
+        if (live) s3[0] += rw * log(S);
+    }
+    set_sync<THREADS>();
+    for (int i = threadIdx.x; i < nt; i += THREADS) {
+        const double xi = x[i], dn = L.den[i], ui = L.u[i];
+        const double acc = set_col_sum(L, L.w, i);
+        const double g = acc - dn + (xi > 0.0 ? ui / xi : 0.0);
+        if (ui > 0.0 && xi > 0.0) s3[0] += ui * log(xi);
+        s3[1] += xi * dn;
+        double mi = 0.0, ri = 0.0;                                   // mi: 0 = outside F (den = 0), -1 = bound, > 0 = 1 / diag(-H)
+        if (dn > 0.0) {
+            if (g < 0.0 && xi * dn < kBoundReads && ui == 0.0) mi = -1.0;
+            else {
+                const double diag = set_col_sum(L, L.hrow, i) + (xi > 0.0 ? ui / (xi * xi) : 0.0);
+                mi = diag > 0.0 ? 1.0 / diag : 1.0;
+                ri = g;
+            }
+        }
+        L.mi[i] = mi; r[i] = ri; L.z[i] = 0.0;
+        const double q = mi > 0.0 ? mi * ri : 0.0;
+        p[i] = q;
+        s3[2] += ri * q;
+    }
+    set_reduce_sum<THREADS, 3>(s3, L.red);
+    const double Fx = s3[0] - s3[1];
+    double rq = s3[2];
+    const double rq_stop = 1e-8 * rq;                               // |r| down by 1e-4 in the preconditioned norm
+    passes++;
+    set_sync<THREADS>();
+    // ---- preconditioned CG on the free components ----
+    for (int it = 0; it < nt && rq > rq_stop && rq > 0.0; it++) {
+        for (int j = threadIdx.x; j < nr; j += THREADS) L.w[j] = L.hrow[j] * set_row_dot<THREADS>(L, p, j);
+        set_sync<THREADS>();
+        double s1[1] = {0.0};
+        for (int i = threadIdx.x; i < nt; i += THREADS) {
+            double hp = 0.0;
+            if (L.mi[i] > 0.0) {
+                const double xi = x[i];
+                hp = set_col_sum(L, L.w, i) + (xi > 0.0 ? L.u[i] / (xi * xi) : 0.0) * p[i];
+            }
+            L.hp[i] = hp;
+            s1[0] += p[i] * hp;
+        }
+        set_reduce_sum<THREADS, 1>(s1, L.red);
+        passes++;
+        if (!(s1[0] > 0.0)) break;
+        const double al = rq / s1[0];
+        double s2[1] = {0.0};
+        for (int i = threadIdx.x; i < nt; i += THREADS) {
+            L.z[i] += al * p[i];
+            const double ri = r[i] - al * L.hp[i];
+            r[i] = ri;
+            const double mi = L.mi[i];
+            if (mi > 0.0) s2[0] += ri * (mi * ri);
+        }
+        set_reduce_sum<THREADS, 1>(s2, L.red);
+        const double beta = s2[0] / rq;
+        rq = s2[0];
+        for (int i = threadIdx.x; i < nt; i += THREADS) { const double mi = L.mi[i]; p[i] = (mi > 0.0 ? mi * r[i] : 0.0) + beta * p[i]; }
+        set_sync<THREADS>();
+    }
+    // ---- projected step, accepted only if F does not fall ----
+    double alpha = 1.0;
+    for (int tr = 0; tr < 4; tr++, alpha *= 0.25) {
+        for (int i = threadIdx.x; i < nt; i += THREADS) {
+            const double mi = L.mi[i], xi = x[i];
+            double xn = 0.0;
+            if (mi > 0.0) xn = fmax(xi + alpha * L.z[i], 0.0);
+            else if (mi < 0.0) xn = alpha == 1.0 ? 0.0 : xi * (1.0 - alpha);
+            L.hp[i] = xn;
+        }
+        set_sync<THREADS>();
+        double s4[3] = {0.0, 0.0, 0.0};    // sum R log S + u log x, sum x den, infeasible
+        for (int j = threadIdx.x; j < nr; j += THREADS) {
+            const double S = set_row_dot<THREADS>(L, L.hp, j), rw = L.rw[j];
+            if (S > 0.0) s4[0] += rw * log(S); else if (rw > 0.0) s4[2] += 1.0;
+        }
+        for (int i = threadIdx.x; i < nt; i += THREADS) {
+            const double xn = L.hp[i], ui = L.u[i];
+            if (ui > 0.0) { if (xn > 0.0) s4[0] += ui * log(xn); else s4[2] += 1.0; }
+            s4[1] += xn * L.den[i];
+        }
+        set_reduce_sum<THREADS, 3>(s4, L.red);
+        passes++;
+        const double Fn = s4[0] - s4[1];
+        if (s4[2] == 0.0 && Fn >= Fx - 1e-13 * fabs(Fx)) {
+            for (int i = threadIdx.x; i < nt; i += THREADS) x[i] = L.hp[i];
+            set_sync<THREADS>();
+            return true;
+        }
+        set_sync<THREADS>();
+    }
+    return false;
+}
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__restrict__ desc, const int32_t *__restrict__ g_tid,
                                                         const double *__restrict__ g_u, const double *__restrict__ row_w,
@@ -164,7 +307,8 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
     const int nt = (int)d.n_t, nr = (int)d.n_r, nnz = (int)d.nnz;
     double *A = smem, *B = A + nt, *Cc = B + nt;
     SetLds L;
-    L.den = Cc + nt; L.u = L.den + nt; L.w = L.u + nt; L.rw = L.w + nr; L.red = L.rw + nr;
+    L.den = Cc + nt; L.u = L.den + nt; L.z = L.u + nt; L.hp = L.z + nt; L.mi = L.hp + nt;
+    L.w = L.mi + nt; L.rw = L.w + nr; L.hrow = L.rw + nr; L.red = L.hrow + nr;
     uint16_t *rp = (uint16_t *)(L.red + emsar::kSetRedDoubles), *ent = rp + (nr + 1), *cp = ent + nnz, *crow = cp + (nt + 1);
     L.rp = rp; L.ent = ent; L.cp = cp; L.crow = crow; L.nt = nt; L.nr = nr;
     for (int i = threadIdx.x; i < nt; i += THREADS) {
@@ -179,7 +323,7 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
     set_sync<THREADS>();
 
     double stepmax = 1.0, delta = __builtin_huge_val();
-    int passes = 0, converged = 0;
+    int passes = 0, converged = 0, cooldown = 0;
     double *res = A;
     for (;;) {
         // pass 1 (plain): B = EM(A); the stopping rule is measured on this step only
@@ -187,7 +331,12 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
         double dloc = 0.0;
         for (int i = threadIdx.x; i < nt; i += THREADS) {
             const double x = A[i], dn = L.den[i];
-            const double y = set_em_update(x, set_em_acc(L, i), L.u[i], dn);
+            const double acc = set_em_acc(L, i);
+            double y = set_em_update(x, acc, L.u[i], dn);
+            // a component the Newton step has put on the boundary stays there under the EM (0 is a fixed point); if the gradient
+            // at 0 has turned positive since, it is re-opened just above 0 and the set is not done
+            const bool reopen = x == 0.0 && dn > 0.0 && acc > dn * (1.0 + 1e-9);
+            if (reopen) y = 1e-9 * fast_rcp(dn);
             B[i] = y;
             double fl = P.abs_floor;
             if (P.count_floor > 0.0 && dn > 0.0) fl = fmax(fl, P.count_floor / dn);
@@ -195,6 +344,7 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
             if (!(dd == dd)) dd = __builtin_huge_val();
             if (y < P.zero_cut && y <= x) dd = 0.0;
             if (fabs(y - x) * (double)(passes + 1 > 1000 ? passes + 1 : 1000) < P.abs_step * 2e5) dd = 0.0;   // projected drift, see emsar_em_params.abs_step
+            if (reopen) dd = 1.0;
             dloc = fmax(dloc, dd);
         }
         delta = set_reduce_max<THREADS>(dloc, L.red);
@@ -256,6 +406,10 @@ __global__ __launch_bounds__(THREADS) void k_solve_sets(const emsar::SetDesc *__
         passes += 2;
         res = A;
         if (passes >= P.max_iter) break;
+        if (P.newton_after >= 0 && passes >= P.newton_after) {
+            if (cooldown > 0) cooldown--;
+            else if (!set_newton_step<THREADS>(L, A, B, Cc, passes)) cooldown = 8;
+        }
     }
     for (int i = threadIdx.x; i < nt; i += THREADS) theta_g[g_tid[d.tid_off + i]] = res[i];
     if (threadIdx.x == 0) { stat[blockIdx.x].passes = passes; stat[blockIdx.x].converged = converged; stat[blockIdx.x].delta = delta; }

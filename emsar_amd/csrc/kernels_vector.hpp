@@ -12,18 +12,33 @@ __global__ void k_fill_start(int n, const double *__restrict__ den, double *__re
     if (t < n) theta[t] = den[t] > 0.0 ? 1.0 : 0.0;  // uniform interior start; tids outside F are defined 0
 }
 
+// Exported far entries of the TILED layout (layout_tiled.hpp): the pass kernel leaves the weight w_r of every row with an
+// exported entry in far_w; the M-step sum of transcript t is acc_t + sum over its exported entries -- gathered here, in the
+// fixed order of far_pos, instead of one scattered atomic per entry in the pass kernel.  ptr == nullptr: no such entries.
+struct FarList { const uint32_t *ptr; const uint32_t *pos; const double *w; };
+__device__ __forceinline__ double far_sum(const FarList &F, int t) {
+    double s = 0.0;
+    if (F.ptr) for (uint32_t q = F.ptr[t], e = F.ptr[t + 1]; q < e; q++) s += F.w[F.pos[q]];
+    return s;
+}
+// out_t += sum of the exported entries (scatter passes: den, iEUMA)
+__global__ __launch_bounds__(256) void k_far_add(int n, const FarList F, double *__restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) { const double s = far_sum(F, t); if (s != 0.0) out[t] += s; }
+}
+
 // theta_out = theta_in * acc / den ; acc <- 0 ; scal.delta = max |dtheta| / (theta_out + floor)
 // grid-stride, one atomicMax per workgroup (hundreds of same-address atomics cost ~12 ns each)
 __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
                                                 const double *__restrict__ den, const double *__restrict__ u /* folded single-tid rows, may be null */,
                                                 double *__restrict__ th_out, double abs_floor, double count_floor, double zero_cut, Scal *scal,
                                                 const uint8_t *__restrict__ kind /* non-null: only KIND_STREAMED transcripts enter the stopping rule */,
-                                                int to_delta1 /* the first (plain) step of a SQUAREM cycle: the cycle's stopping rule */) {
+                                                int to_delta1 /* the first (plain) step of a SQUAREM cycle: the cycle's stopping rule */, const FarList F) {
     __shared__ double red[4];
     double d = 0.0;
     const double abs_step = scal->abs_step_cur;      // written by k_cycle_begin, nobody writes it during a pass
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
-        double a = acc[t], dn = den[t], x = th_in[t];
+        double a = acc[t] + far_sum(F, t), dn = den[t], x = th_in[t];
         // a row {t} contributes R/theta_t to acc_t, i.e. R to theta_t*acc_t: added analytically (TILED layout)
         double y = dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
         th_out[t] = y;
@@ -75,12 +90,13 @@ __device__ __forceinline__ double em_new_theta(double x, double a, double dn, co
     return dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
 }
 __global__ __launch_bounds__(256) void k_update_p2(int n, const double *__restrict__ th0, const double *__restrict__ th1, double *__restrict__ acc,
-                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th2, Scal *scal) {
+                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th2, Scal *scal,
+                                                   const FarList F) {
     __shared__ double red[4];
     double r2 = 0, v2 = 0, p1 = 0, l1 = 0;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
         const double x = th1[t], dn = den[t];
-        const double y = em_new_theta(x, acc[t], dn, u, t);
+        const double y = em_new_theta(x, acc[t] + far_sum(F, t), dn, u, t);
         th2[t] = y;
         acc[t] = 0.0;
         const double r = x - th0[t], v = (y - x) - r;
@@ -124,12 +140,13 @@ __global__ __launch_bounds__(256) void k_sq_extrap_ll(int n, const double *__res
     }
 }
 __global__ __launch_bounds__(256) void k_update_p3(int n, const double *__restrict__ thx, const double *__restrict__ th2, double *__restrict__ acc,
-                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th0, Scal *scal) {
+                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th0, Scal *scal,
+                                                   const FarList F) {
     const double s = scal->s_used;
     const bool extrap = s > 1.0;
     const bool ok = !extrap || (scal->ll[2].v - scal->penx.v >= scal->ll[1].v - scal->pen1.v);
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
-        const double y = em_new_theta(thx[t], acc[t], den[t], u, t);
+        const double y = em_new_theta(thx[t], acc[t] + far_sum(F, t), den[t], u, t);
         acc[t] = 0.0;
         th0[t] = ok ? y : th2[t];
     }

@@ -1,24 +1,32 @@
 // layout_tiled.hpp -- host-side construction of the TILED HBM layout (pure C++, no HIP calls).
 //
-// Goal: a pass whose inner loops touch only LDS with 16-bit operands, with no atomics on the hot path and no
-// workgroup barrier between the E-step and the M-step.
+// Goal: a pass whose inner loops touch only LDS with 10-bit operands, with no atomics in the inner loops, no workgroup
+// barrier between the E-step and the M-step, and a dictionary (theta / accumulator window in LDS) that is loaded and flushed
+// once for MANY slices.
 //
 //   * rows with ONE tid never reach the kernel: they are folded into a per-transcript count vector u
 //     (acc_t += u_t / theta_t is applied analytically in k_update);
-//   * rows with 2..kMaxRowLen tids are sorted by (block(anchor tid), length class, anchor tid), anchor = median tid, like the WINDOWED
-//     layout and cut into TILES of at most 3072 rows whose distinct tids fit a 959-entry chunk-local
-//     DICTIONARY: the contiguous range [lo, lo+near_n) that covers most of the tile's tids plus an explicit list
-//     of far tids.  Every stored operand is a 10-BIT id (dictionary slot < 1024, slice row < 1024), three to a dword;
-//   * a tile has up to 4 SLICES of 768 rows; one wavefront owns one slice for the whole pass:
-//       forward index (E-step, row sums): column-major [k][768]; lane l owns rows 12l..12l+11, so column j of its
-//         rows is ONE int4 of twelve 10-bit ids; padding points at a zero slot (no branches);
-//       backward index (M-step, column sums) OF THE SAME 768 ROWS: for every dictionary column with >= 4 entries in
-//         the slice, its slice-local rows cut into segments of 11 row ids headed by the column id
-//         (12 x 10 bit = one int4).  Segments are dealt to lanes in contiguous column order (a lane keeps the running
-//         sum of a column in a register), but stored interleaved so that wave loads stay 1 KiB contiguous.
-//         Columns with < 4 entries go to a COO list of (column, row) id pairs.
-//     Because the transposed index is per slice, the wave that computed w_r for its 768 rows is the only consumer
-//     of them: E-step and M-step need no workgroup barrier in between;
+//   * rows with 2..kMaxRowLen tids are sorted by (block(anchor tid), length class, anchor tid), anchor = median tid, and cut
+//     into SLICES of at most 768 rows; one wavefront processes one slice at a time:
+//       forward index (E-step, row sums): column-major [k][768]; row p of the slice is field p/64 of lane p%64, so column j
+//         of a lane's 12 rows is ONE int4 of twelve 10-bit dictionary ids; padding points at a zero slot (no branches);
+//       backward index (M-step, column sums) OF THE SAME 768 ROWS: for every dictionary column with >= 4 entries in the
+//         slice, its slice-local rows cut into segments of 11 row ids headed by the column id (12 x 10 bit = one int4).
+//         Segments are dealt to lanes in contiguous column order (a lane keeps the running sum of a column in a register),
+//         but stored interleaved so that wave loads stay 1 KiB contiguous.  Columns with < 4 entries go to a COO list;
+//   * FAR ENTRIES.  An entry more than kFarReach tids away from its row's anchor (a read that also hits a transcript of another
+//     gene family) would need a dictionary slot of its own, a scattered theta gather and a scattered flush atomic -- on
+//     BASELINE config 3 such entries were 0.6 % of the entries but 19 % of all dictionary slots and two thirds of the flush
+//     atomics.  The first far entry of a row is therefore EXPORTED: the row is placed in one of the last fields of its slice
+//     (field 11, then 10: at most 128 such rows per slice), the far tid goes to a per-slice FAR BLOCK of 64 tids that the
+//     lanes of the wave gather straight from theta into the register that holds that field's row sum, and the row's weight
+//     w_r is written to far_w[block][lane]; the update kernels add sum_e far_w[far_pos[e]] over the exported entries e of
+//     transcript t (far_ptr / far_pos, a CSR by transcript) to acc_t -- no dictionary slot, no atomic, fixed summation order.
+//     Further far entries of the same row (rare) keep explicit dictionary slots (the group's far list);
+//   * consecutive slices whose near entries fit one window of <= 959 transcripts form a GROUP: one dictionary, loaded
+//     once, flushed once; the waves of the workgroup take the group's slices one after another (no barrier in between);
+//   * the slices are cut into CHUNKS of equal work, one workgroup each (as many chunks as the device holds workgroups, so
+//     that every workgroup is resident from the start and all of them finish together); a chunk is one or more groups;
 //   * rows longer than kMaxRowLen go to a leftover CSR processed by the generic kernel.
 #pragma once
 #include <algorithm>
@@ -41,21 +49,22 @@
 
 namespace emsar {
 
-constexpr int kTileSlices = 4;         // wavefronts per workgroup
+constexpr int kTileWaves = 4;          // wavefronts per workgroup
 constexpr int kRowsPerLane = 12;       // twelve 10-bit ids per int4
 constexpr int kTileSliceRows = 64 * kRowsPerLane;   // 768
-constexpr int kTileRows = kTileSlices * kTileSliceRows;
-constexpr int kTileDict = 959;         // theta + acc windows in LDS: 2 x 7.5 KiB; +1 zero slot (5 workgroups per CU)
-constexpr int64_t kFragRows = 1 << 21;   // sorted rows per independently tiled fragment (build_tiled)
+constexpr int kTileDict = 959;         // theta + acc windows in LDS: 2 x 7.5 KiB; +1 zero slot
+constexpr int64_t kFragRows = 1 << 21;   // sorted rows per independently sliced fragment (build_tiled)
 constexpr int kMaxRowLen = 768;        // longer rows -> leftover CSR (a row must fit one dictionary)
 constexpr int kSegRows = 11;           // row ids per backward segment (plus 1 header = 12 x 10 bit = one int4)
 constexpr int kSliceDwords = kTileSliceRows / 3;    // dwords per forward column of a slice (256 = 1 KiB)
+constexpr int kFarReach = 200;         // |tid - anchor| beyond this: a far entry (block 512 + 2 x 200 < 959)
+constexpr int kMaxFarBlocks = 2;       // far blocks (64 exported rows each) per slice
+constexpr int64_t kSliceEntries = 65535;   // entries of one slice (16-bit COO count)
 
 // field i (0..11) of a packed int4: dword i/3, bits 10*(i%3) .. +10
 inline void pack10(uint32_t *q, int i, uint32_t id) { q[i / 3] |= (id & 0x3FFu) << (10 * (i % 3)); }
 inline uint32_t unpack10(const uint32_t *q, int i) { return (q[i / 3] >> (10 * (i % 3))) & 0x3FFu; }
 constexpr int kDenseMin = 4;           // columns with fewer entries in a slice use the COO list
-constexpr int64_t kTileEntries = 65536;
 
 // vectors whose resize(n) leaves the new elements uninitialised (resize(n, v) still fills): the big index arrays are
 // sized once and filled by several threads, a zero fill by one thread first would cost as much as the copy
@@ -68,21 +77,30 @@ template <class T> struct no_init_alloc : std::allocator<T> {
 using u32_vec = std::vector<uint32_t, no_init_alloc<uint32_t>>;
 using i64_vec = std::vector<int64_t, no_init_alloc<int64_t>>;
 
-struct Tile {                // 64 bytes
-    uint64_t fwd_off;        // byte offset into fwd (multiple of 1024)
-    uint64_t bwd_off;        // byte offset into bwd (multiple of 1024)
-    uint32_t row_base;       // first row slot of the tile (multiple of 768); slot = row_base + slice*768 + 64*i + lane
-    uint32_t far_off;        // index of the tile's first far tid in far_tid[]
-    uint32_t coo_off;        // index of the tile's first pair in coo[]
+struct SliceDesc {           // 32 bytes; slice i owns row slots [768 i, 768 i + 768): slot = 768 i + 64 field + lane
+    uint32_t fwd_kib;        // forward block: int4 index = 64 * fwd_kib   (1 KiB = one column of the slice)
+    uint32_t bwd_kib;        // backward block, same unit (1 KiB = one segment per lane)
+    uint32_t coo_off;        // first pair in coo[]
+    uint32_t far_blk;        // first far block of the slice: block j serves field 11 - j
+    uint16_t k;              // forward columns (padded row length, the exported entry not counted)
+    uint16_t m;              // backward segments (int4) per lane
+    uint16_t coo_n;          // COO pairs
+    uint16_t nf;             // far blocks (0..kMaxFarBlocks)
+    uint32_t n_rows;         // rows stored (<= 768)
+    uint32_t pad0;
+};
+static_assert(sizeof(SliceDesc) == 32, "SliceDesc must stay 32 bytes");
+
+struct GroupDesc {           // 32 bytes: consecutive slices that share one dictionary
     int32_t lo;              // dictionary slot d < near_n  <->  tid lo + d
     uint16_t near_n, far_n;  // slot near_n + i <-> far_tid[far_off + i]; zero slot = near_n + far_n
-    uint16_t n_slices;       // <= 4
-    uint16_t pad0;
-    uint16_t k[4];           // padded row length of each slice's forward index
-    uint16_t m[4];           // backward segments (int4) per lane of each slice
-    uint16_t coo_n[4];       // COO pairs of each slice
+    uint32_t far_off;
+    uint32_t slice_begin, slice_end;
+    uint32_t pad0[3];
 };
-static_assert(sizeof(Tile) == 64, "Tile must stay 64 bytes");
+static_assert(sizeof(GroupDesc) == 32, "GroupDesc must stay 32 bytes");
+
+struct ChunkDesc { uint32_t group_begin, group_end; };   // one workgroup
 
 struct TiledLayout {
     int64_t n_rows = 0, nnz = 0;
@@ -90,21 +108,29 @@ struct TiledLayout {
     // singletons: folded rows
     std::vector<uint32_t> single_row;   // original row index
     std::vector<int32_t> single_tid;
-    // tiles
-    std::vector<Tile> tiles;
+    // slices, groups, chunks
+    std::vector<SliceDesc> slices;
+    std::vector<GroupDesc> groups;
+    std::vector<ChunkDesc> chunks;
     i64_vec slot_row;                   // row slot -> original row, or merged-row id when `merged` (-1 = padding)
     bool merged = false;                // identical rows were merged: a slot stands for mem_row[mem_ptr[id] .. mem_ptr[id+1])
     std::vector<uint64_t> mem_ptr;
     std::vector<uint32_t> mem_row;
     u32_vec fwd, bwd;                   // packed 10-bit ids
     std::vector<uint32_t> coo;          // (col_id << 16) | row_id
-    std::vector<int32_t> far_tid;
-    // leftover rows (too long for a tile): plain CSR + original row ids
+    std::vector<int32_t> far_tid;       // explicit dictionary far lists of the groups
+    // exported far entries
+    std::vector<int32_t> far_blk_tid;   // [n_far_blocks][64]: far tid of the row in (block, lane), -1 = none
+    std::vector<uint32_t> far_ptr;      // [n_tx + 1]: exported entries by transcript ...
+    std::vector<uint32_t> far_pos;      // ... -> 64 * block + lane (index into far_w)
+    // leftover rows (too long for a slice): plain CSR + original row ids
     std::vector<uint64_t> left_ptr;
     std::vector<int32_t> left_col;
     std::vector<uint32_t> left_row;
-    int64_t tiled_entries = 0, far_entries = 0, coo_entries = 0, n_fslices = 0, padded_slots = 0;
+    int64_t tiled_entries = 0, far_entries = 0 /* explicit dictionary far slots used, summed over entries */, exported_entries = 0,
+            coo_entries = 0, padded_slots = 0;
     int64_t n_slots() const { return (int64_t)slot_row.size(); }
+    int64_t n_far_blocks() const { return (int64_t)far_blk_tid.size() / 64; }
 };
 
 // fn(0) on the calling thread, fn(1..nt-1) on threads of their own.  An allocation failure inside a thread must not end the
@@ -125,36 +151,43 @@ inline void run_on_threads(int nt, F fn) {
     if (oom.load()) throw std::bad_alloc();
 }
 
-// Every range a kernel derives from a tile descriptor must lie inside the arrays it indexes -- k_pass_tiled has no bounds
-// checks, an out-of-range read is a GPU memory fault.  Checked on the host for every layout before it is uploaded
-// (build_tiled's last step) and again by check_tiled.  Per tile, as the kernels compute them (kernels_tiled.hpp):
-//   forward   int4 reads  [fwd_off/16 + 64*sum_{s'<s} k[s'], + 64*k[s])        k[s] >= 1 for every slice (load8_clamped reads n-1)
-//   backward  int4 reads  [bwd_off/16 + 64*sum m[s'], + 64*m[s])
-//   COO       dword reads [coo_off + sum coo_n[s'], + coo_n[s])
-//   far list  dword reads [far_off, far_off + far_n)
-//   rows      slots       [row_base, row_base + 768*n_slices)                   (weights, scatter values, slot_row)
-//   dictionary near_n + far_n <= kTileDict, tids lo .. lo + near_n - 1 and every far tid inside [0, n_tx)
+// Every range a kernel derives from a descriptor must lie inside the arrays it indexes -- k_pass_tiled has no bounds checks, an
+// out-of-range read is a GPU memory fault.  Checked on the host for every layout before it is uploaded (build_tiled's last
+// step) and again by check_tiled.  As the kernels compute them (kernels_tiled.hpp):
+//   chunk     groups [group_begin, group_end) inside groups[]
+//   group     slices [slice_begin, slice_end) inside slices[]; dictionary near_n + far_n <= kTileDict, tids lo .. lo + near_n - 1
+//             and the far list [far_off, far_off + far_n) inside [0, n_tx)
+//   slice i   forward   int4 reads [64 fwd_kib, 64 (fwd_kib + k))        k >= 1 (load8_clamped reads position n - 1)
+//             backward  int4 reads [64 bwd_kib, 64 (bwd_kib + m))
+//             COO       dword reads [coo_off, coo_off + coo_n)
+//             far blocks [far_blk, far_blk + nf), nf <= kMaxFarBlocks, every tid in it -1 or inside [0, n_tx)
+//             row slots [768 i, 768 i + 768)   (weights, scatter values, slot_row)
+//   far_pos   every entry < 64 * n_far_blocks
 // 0 = fine, else a negative code naming the first violated rule.
 inline int check_tiled_extents(const TiledLayout &L) {
     const uint64_t n_fwd = (uint64_t)L.fwd.size() / 4, n_bwd = (uint64_t)L.bwd.size() / 4;     // int4 units
-    for (const Tile &T : L.tiles) {
-        if (T.n_slices < 1 || T.n_slices > kTileSlices) return -21;
-        if ((int)T.near_n + (int)T.far_n > kTileDict || T.near_n < 1) return -22;
-        if (T.lo < 0 || (int64_t)T.lo + T.near_n > (int64_t)L.n_tx) return -23;
-        if ((uint64_t)T.far_off + T.far_n > (uint64_t)L.far_tid.size()) return -24;
-        for (uint32_t i = 0; i < T.far_n; i++) { const int32_t t = L.far_tid[(size_t)T.far_off + i]; if (t < 0 || t >= L.n_tx) return -24; }
-        if (T.fwd_off % 1024 || T.bwd_off % 1024 || T.row_base % kTileSliceRows) return -25;
-        uint64_t kf = 0, mb = 0, cn = 0;
-        for (int s = 0; s < kTileSlices; s++) {
-            if (s < (int)T.n_slices) { if (T.k[s] < 1 || T.k[s] > kMaxRowLen) return -26; }
-            else if (T.k[s] || T.m[s] || T.coo_n[s]) return -26;
-            kf += T.k[s]; mb += T.m[s]; cn += T.coo_n[s];
-        }
-        if (T.fwd_off / 16 + 64 * kf > n_fwd) return -27;
-        if (T.bwd_off / 16 + 64 * mb > n_bwd) return -28;
-        if ((uint64_t)T.coo_off + cn > (uint64_t)L.coo.size()) return -29;
-        if ((uint64_t)T.row_base + (uint64_t)T.n_slices * kTileSliceRows > (uint64_t)L.slot_row.size()) return -30;
+    const uint64_t n_blk = (uint64_t)L.far_blk_tid.size() / 64;
+    if (L.far_blk_tid.size() % 64) return -20;
+    for (const ChunkDesc &C : L.chunks) if (C.group_begin > C.group_end || C.group_end > L.groups.size()) return -21;
+    for (const GroupDesc &G : L.groups) {
+        if (G.slice_begin >= G.slice_end || G.slice_end > L.slices.size()) return -21;
+        if ((int)G.near_n + (int)G.far_n > kTileDict || G.near_n < 1) return -22;
+        if (G.lo < 0 || (int64_t)G.lo + G.near_n > (int64_t)L.n_tx) return -23;
+        if ((uint64_t)G.far_off + G.far_n > (uint64_t)L.far_tid.size()) return -24;
+        for (uint32_t i = 0; i < G.far_n; i++) { const int32_t t = L.far_tid[(size_t)G.far_off + i]; if (t < 0 || t >= L.n_tx) return -24; }
     }
+    for (const SliceDesc &D : L.slices) {
+        if (D.k < 1 || D.k > kMaxRowLen || D.nf > kMaxFarBlocks || D.n_rows < 1 || D.n_rows > (uint32_t)kTileSliceRows) return -26;
+        if (64 * ((uint64_t)D.fwd_kib + D.k) > n_fwd) return -27;
+        if (64 * ((uint64_t)D.bwd_kib + D.m) > n_bwd) return -28;
+        if ((uint64_t)D.coo_off + D.coo_n > (uint64_t)L.coo.size()) return -29;
+        if ((uint64_t)D.far_blk + D.nf > n_blk) return -33;
+    }
+    for (int32_t t : L.far_blk_tid) if (t < -1 || t >= L.n_tx) return -33;
+    if ((uint64_t)L.slices.size() * kTileSliceRows != (uint64_t)L.slot_row.size()) return -30;
+    if (L.far_ptr.size() != (size_t)L.n_tx + 1 || L.far_ptr.front() != 0 || L.far_ptr.back() != L.far_pos.size()) return -34;
+    for (size_t t = 0; t + 1 < L.far_ptr.size(); t++) if (L.far_ptr[t] > L.far_ptr[t + 1]) return -34;
+    for (uint32_t p : L.far_pos) if ((uint64_t)p >= 64 * n_blk) return -34;
     if (L.left_ptr.size() != L.left_row.size() + 1 || (L.left_ptr.empty() ? 0 : L.left_ptr.back()) != (uint64_t)L.left_col.size()) return -31;
     if (L.single_row.size() != L.single_tid.size()) return -32;
     return 0;
@@ -164,8 +197,9 @@ inline int check_tiled_extents(const TiledLayout &L) {
 // their members' weights -- what the reference's update_ReadCounts does when it counts reads per segment
 // (emsar_functions.c:838-943).  Every quantity the library computes is a sum over rows of a function of the row's tid
 // set times a per-row weight, so the merge is exact up to summation order.
+// n_wg_slots: workgroups the device holds at once (4 per CU): the number of equal-work chunks.
 inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in, const int32_t *col_idx_in, TiledLayout &out,
-                       bool merge_rows = false) {
+                       bool merge_rows = false, int n_wg_slots = 1024) {
     if (n_rows >= (int64_t)1 << 32) return -1;
     out = TiledLayout();
     const uint64_t *row_ptr = row_ptr_in;
@@ -252,6 +286,10 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         run_on_threads(nt, [&](int t) { fn(t, n * t / nt, n * (t + 1) / nt); });
         return nt;
     };
+    int far_reach = kFarReach;            // entries further than this from the row's anchor are far
+    if (const char *e = getenv("EMSAR_HIP_FAR_REACH")) { int v = atoi(e); if (v >= 1 && v <= kFarReach) far_reach = v; }
+    bool far_export = true;               // EMSAR_HIP_FAR_EXPORT=0: no entry is exported, every far entry keeps a dictionary slot
+    if (const char *e = getenv("EMSAR_HIP_FAR_EXPORT")) far_export = atoi(e) != 0;
     std::vector<int32_t> mintid((size_t)n_rows, -1);      // the anchor tid of every tiled row (see below)
     bool anchor_median = true;
     if (const char *e = getenv("EMSAR_HIP_TILE_ANCHOR")) anchor_median = atoi(e) != 0;
@@ -288,7 +326,17 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 if (len == 0) continue;
                 const uint32_t r_orig = merge_rows ? orig_of_merged[(size_t)r] : (uint32_t)r;   // singles / long rows are never merged
                 if (len == 1) { P.single_row.push_back(r_orig); P.single_tid.push_back(col_idx[b]); continue; }
-                if (len > (uint64_t)kMaxRowLen) {
+                bool too_wide = false;                        // near span + far entries beyond one dictionary (only possible for len > 550)
+                if (len > (uint64_t)(kTileDict - 2 * kFarReach - 1) && len <= (uint64_t)kMaxRowLen) {
+                    const int32_t a = mintid[(size_t)r];
+                    int32_t lo = a, hi = a; int64_t nfar = 0;
+                    for (uint64_t k = b; k < e; k++) {
+                        const int32_t t = col_idx[k], dist = t > a ? t - a : a - t;
+                        if (dist > far_reach) nfar++; else { lo = std::min(lo, t); hi = std::max(hi, t); }
+                    }
+                    too_wide = (int64_t)hi - lo + 1 + nfar > kTileDict;
+                }
+                if (len > (uint64_t)kMaxRowLen || too_wide) {
                     P.left_row.push_back(r_orig);
                     P.left_col.insert(P.left_col.end(), col_idx + b, col_idx + e);
                     P.left_len.push_back(len);
@@ -316,12 +364,9 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     // blocks stay small; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
     int32_t block = 512;
     if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 900) block = v; }
-    int64_t tile_rows = kTileRows;
-    if (const char *e = getenv("EMSAR_HIP_TILE_ROWS")) { int v = atoi(e); if (v >= kTileSliceRows && v <= kTileRows) tile_rows = v / kTileSliceRows * kTileSliceRows; }
     int dense_min = kDenseMin;
     if (const char *e = getenv("EMSAR_HIP_TILE_DENSE")) { int v = atoi(e); if (v >= 1 && v <= 64) dense_min = v; }
-    bool cut_at_slices = true;
-    if (const char *e = getenv("EMSAR_HIP_TILE_CUT")) cut_at_slices = atoi(e) != 0;
+    if (const char *e = getenv("EMSAR_HIP_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= (1 << 20)) n_wg_slots = v; }
     const auto tp1 = t_now();
     // ---- sort: pass A by anchor tid, pass B by (block, length class); both stable ----
     // A stable counting sort over chunks of the input: one histogram per chunk, offsets ordered (key, chunk), then every
@@ -360,139 +405,239 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     std::vector<uint32_t>().swap(pa);
     const auto tp2 = t_now();
 
-    // ---- tiles ----
-    // The sorted rows are cut into fragments of kFragRows rows; every fragment is tiled on its own (into a private
-    // TiledLayout) and the fragments are concatenated.  The cut points depend on the data only, so the layout is the same
-    // whatever the number of host threads that happen to build it.
-    auto form_tiles = [&](int64_t range_begin, int64_t range_end, TiledLayout &out) -> int {
-    std::vector<int32_t> stamp((size_t)n_tx, -1), loc((size_t)n_tx, 0);
-        std::vector<int32_t> distinct;
-        std::vector<uint32_t> pairs, sorted;   // (col_local << 16) | row_in_slice
-        std::vector<uint32_t> ccount, fill;
-        std::vector<uint32_t> segs;            // 4 dwords per segment
-        int64_t i0 = range_begin;
-        int32_t tile_id = 0;
-        const int64_t n_act = range_end;      // rows beyond the range belong to another fragment
-        while (i0 < n_act) {
-            // 1. how many rows fit: row cap, entry cap, distinct-tid cap
-            distinct.clear();
-            int64_t ents = 0, i1 = i0;
-            while (i1 < n_act && i1 - i0 < tile_rows) {
-                uint32_t r = perm[(size_t)i1];
-                uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-                if (i1 > i0 && ents + (int64_t)(e - b) > kTileEntries) break;
-                size_t before = distinct.size();
-                for (uint64_t k = b; k < e; k++) {
-                    int32_t t = col_idx[k];
-                    if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
+
+    // ---- P1: slices ----
+    // The sorted rows are cut into fragments of kFragRows rows; every fragment is cut into slices on its own.  The cut
+    // points depend on the data only, so the layout is the same whatever the number of host threads that build it.
+    // A row is FAR when it has an entry more than far_reach tids from its anchor and its slice still has room in a far
+    // block; such rows fill the slice from the top (block 0 = field 11, block 1 = field 10), the others from the bottom.
+    struct SliceTmp {
+        int64_t begin = 0, end = 0;          // sorted-row range
+        int32_t nmin = 0, nmax = -1;         // tid range of the entries that need dictionary slots by position (near entries)
+        uint32_t n_norm = 0, n_far = 0, k = 0;
+        int64_t ents = 0;                    // stored entries (exported ones not counted)
+        std::vector<int32_t> expl;           // distinct un-exported far tids (explicit dictionary slots), ascending
+    };
+    auto is_far = [&](int32_t t, int32_t anchor) { return (t > anchor ? t - anchor : anchor - t) > far_reach; };
+    // index (within the row) of the entry that would be exported, or -1
+    auto export_index = [&](uint32_t r) -> int64_t {
+        if (!far_export) return -1;
+        const int32_t a = mintid[r];
+        for (uint64_t q = row_ptr[r]; q < row_ptr[r + 1]; q++) if (is_far(col_idx[q], a)) return (int64_t)(q - row_ptr[r]);
+        return -1;
+    };
+    auto cut_slices = [&](int64_t range_begin, int64_t range_end, std::vector<SliceTmp> &dst) {
+        std::vector<int32_t> stamp((size_t)n_tx, -1);
+        int32_t sid = 0;
+        int64_t i = range_begin;
+        while (i < range_end) {
+            SliceTmp S;
+            S.begin = i;
+            int32_t nmin = INT32_MAX, nmax = -1;
+            std::vector<int32_t> row_expl;
+            for (; i < range_end; i++) {
+                const uint32_t r = perm[(size_t)i];
+                const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+                const int32_t a = mintid[r];
+                const int64_t ex = export_index(r);
+                const bool far_row = ex >= 0 && S.n_far < (uint32_t)(64 * kMaxFarBlocks);
+                const uint32_t n_norm1 = S.n_norm + (far_row ? 0 : 1), n_far1 = S.n_far + (far_row ? 1 : 0);
+                const int64_t stored = (int64_t)(e - b) - (far_row ? 1 : 0);
+                int32_t lo1 = nmin, hi1 = nmax;
+                row_expl.clear();
+                for (uint64_t q = b; q < e; q++) {
+                    if (far_row && (int64_t)(q - b) == ex) continue;
+                    const int32_t t = col_idx[q];
+                    if (is_far(t, a)) { if (stamp[(size_t)t] != sid && std::find(row_expl.begin(), row_expl.end(), t) == row_expl.end()) row_expl.push_back(t); }
+                    else { lo1 = std::min(lo1, t); hi1 = std::max(hi1, t); }
                 }
-                if (i1 > i0 && (int64_t)distinct.size() > kTileDict) {   // undo this row, close the tile
-                    for (size_t q = before; q < distinct.size(); q++) stamp[(size_t)distinct[q]] = -1;
-                    distinct.resize(before);
-                    break;
+                if (S.n_norm + S.n_far > 0) {
+                    const bool rows_full = n_norm1 + 64 * ((n_far1 + 63) / 64) > (uint32_t)kTileSliceRows;
+                    const bool ents_full = S.ents + stored > kSliceEntries;
+                    const int64_t span = hi1 >= lo1 ? (int64_t)hi1 - lo1 + 1 : 0;
+                    const bool dict_full = span + (int64_t)S.expl.size() + (int64_t)row_expl.size() > kTileDict;
+                    if (rows_full || ents_full || dict_full) break;
                 }
-                ents += (int64_t)(e - b);
-                i1++;
+                S.n_norm = n_norm1; S.n_far = n_far1; S.ents += stored;
+                S.k = std::max<uint32_t>(S.k, (uint32_t)stored);
+                nmin = lo1; nmax = hi1;
+                for (int32_t t : row_expl) { stamp[(size_t)t] = sid; S.expl.push_back(t); }
             }
-            if ((int64_t)distinct.size() > kTileDict) return -3;       // a single row with too many tids: excluded by kMaxRowLen
-            // a tile closed by the dictionary or entry cap in the middle of a slice would pad that slice with empty rows
-            // (forward bytes and gathers for nothing): give the rows of the started slice to the next tile instead
-            if (cut_at_slices && i1 < n_act && i1 - i0 > kTileSliceRows && (i1 - i0) % kTileSliceRows != 0) {
-                const int64_t keep = (i1 - i0) / kTileSliceRows * kTileSliceRows;
-                for (int32_t t : distinct) stamp[(size_t)t] = -1;
-                distinct.clear();
-                i1 = i0 + keep;
-                for (int64_t i = i0; i < i1; i++) {
-                    uint32_t r = perm[(size_t)i];
-                    for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
-                        int32_t t = col_idx[k];
-                        if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
-                    }
+            S.end = i;
+            S.nmin = nmin == INT32_MAX ? 0 : nmin; S.nmax = nmax;
+            std::sort(S.expl.begin(), S.expl.end());
+            dst.push_back(std::move(S));
+            sid++;
+        }
+    };
+    std::vector<SliceTmp> st;
+    {
+        int64_t frag_rows = kFragRows;
+        if (const char *e = getenv("EMSAR_HIP_FRAG_ROWS")) { long long v = atoll(e); if (v >= kTileSliceRows) frag_rows = v; }   // tests: many fragments on small inputs
+        const int64_t n_frag = std::max<int64_t>(1, (n_act + frag_rows - 1) / frag_rows);
+        std::vector<std::vector<SliceTmp>> frag((size_t)n_frag);
+        const int nthr = (int)std::min<int64_t>(n_frag, std::max(1, n_host));
+        std::atomic<int64_t> next{0};
+        run_on_threads(nthr, [&](int) {
+            for (;;) {
+                const int64_t g = next.fetch_add(1);
+                if (g >= n_frag) break;
+                cut_slices(g * frag_rows, std::min(n_act, (g + 1) * frag_rows), frag[(size_t)g]);
+            }
+        });
+        size_t ns = 0;
+        for (auto &f : frag) ns += f.size();
+        st.reserve(ns);
+        for (auto &f : frag) { for (auto &x : f) st.push_back(std::move(x)); std::vector<SliceTmp>().swap(f); }
+    }
+    const int64_t n_slices = (int64_t)st.size();
+    if (n_slices * kTileSliceRows >= ((int64_t)1 << 32)) return -1;
+    const auto tp3 = t_now();
+
+    // ---- P2: chunks of equal work, groups inside a chunk ----
+    // work of a slice ~ the bytes it streams: k forward columns + one backward int4 per 11 entries (+ a fixed cost per slice)
+    auto work_of = [](const SliceTmp &S) { return (int64_t)S.k * 1024 + S.ents * 16 / kSegRows + 2048; };
+    {
+        int64_t total = 0;
+        for (const auto &S : st) total += work_of(S);
+        const int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(n_slices, n_wg_slots));
+        std::vector<int32_t> stamp((size_t)n_tx, -1);
+        int32_t gid = 0;
+        int64_t done = 0, s = 0;
+        for (int64_t c = 0; c < n_chunks && s < n_slices; c++) {
+            // slices [s, e): up to the point where the running work reaches (c + 1) / n_chunks of the total; at least one slice
+            const int64_t target = total * (c + 1) / n_chunks;
+            int64_t e = s;
+            while (e < n_slices && (e == s || done + work_of(st[(size_t)e]) / 2 <= target) && (n_slices - e) > (n_chunks - 1 - c)) { done += work_of(st[(size_t)e]); e++; }
+            if (c == n_chunks - 1) while (e < n_slices) { done += work_of(st[(size_t)e]); e++; }
+            ChunkDesc C;
+            C.group_begin = (uint32_t)out.groups.size();
+            // groups: consecutive slices while their near range plus the explicit far tids fit one dictionary
+            int64_t g0 = s;
+            while (g0 < e) {
+                GroupDesc G;
+                std::memset(&G, 0, sizeof G);
+                int32_t lo = INT32_MAX, hi = -1;
+                std::vector<int32_t> expl;
+                int64_t g1 = g0;
+                for (; g1 < e; g1++) {
+                    const SliceTmp &S = st[(size_t)g1];
+                    int32_t lo1 = lo, hi1 = hi;
+                    if (S.nmax >= S.nmin) { lo1 = std::min(lo1, S.nmin); hi1 = std::max(hi1, S.nmax); }
+                    size_t add = 0;
+                    for (int32_t t : S.expl) if (stamp[(size_t)t] != gid) add++;
+                    const int64_t span = hi1 >= lo1 ? (int64_t)hi1 - lo1 + 1 : 0;
+                    if (g1 > g0 && span + (int64_t)(expl.size() + add) > kTileDict) break;
+                    lo = lo1; hi = hi1;
+                    for (int32_t t : S.expl) if (stamp[(size_t)t] != gid) { stamp[(size_t)t] = gid; expl.push_back(t); }
                 }
+                // explicit far tids that fall inside the window after all need no slot of their own
+                std::sort(expl.begin(), expl.end());
+                if (hi < lo) { lo = expl.empty() ? 0 : expl[0]; hi = lo; }      // a group of rows with far entries only
+                G.lo = lo;
+                G.near_n = (uint16_t)(hi - lo + 1);
+                G.far_off = (uint32_t)out.far_tid.size();
+                for (int32_t t : expl) if (t < lo || t > hi) out.far_tid.push_back(t);
+                G.far_n = (uint16_t)(out.far_tid.size() - G.far_off);
+                G.slice_begin = (uint32_t)g0; G.slice_end = (uint32_t)g1;
+                out.groups.push_back(G);
+                gid++;
+                g0 = g1;
             }
-            // 2. dictionary: the contiguous tid range [distinct[a], distinct[c]] that covers the MOST of the tile's
-            //    tids while (range length + tids outside it) still fits; the tids outside (cross-family hits on
-            //    either side) go to the explicit far list.  slots(a,c) = n + (tids missing inside the range).
-            std::sort(distinct.begin(), distinct.end());
-            const size_t n = distinct.size();
-            size_t best_a = 0, best_c = 0, a = 0;
-            for (size_t c = 0; c < n; c++) {
-                while ((int64_t)n + ((int64_t)distinct[c] - distinct[a]) - (int64_t)(c - a) > kTileDict) a++;
-                if (c == 0 || c - a > best_c - best_a) { best_a = a; best_c = c; }
-            }
-            const int32_t lo = distinct[best_a];
-            const int32_t near_n = distinct[best_c] - lo + 1;
-            const int32_t far_n = (int32_t)(n - (best_c - best_a + 1));
-            Tile T;
-            std::memset(&T, 0, sizeof T);
-            T.lo = lo; T.near_n = (uint16_t)near_n; T.far_n = (uint16_t)far_n;
-            T.far_off = (uint32_t)out.far_tid.size();
-            for (size_t q = 0; q < distinct.size(); q++) {
-                int32_t t = distinct[q];
-                if (t >= lo && t - lo < near_n) loc[(size_t)t] = t - lo;
-                else { loc[(size_t)t] = near_n + (int32_t)(out.far_tid.size() - T.far_off); out.far_tid.push_back(t); }
-            }
-            const int nd = near_n + far_n;
-            const uint32_t zero_id = (uint32_t)nd;                         // th_w[nd] = 0
-            const uint32_t pad_row = (uint32_t)kTileSliceRows;             // w_r[768] of every slice = 0
-            const int64_t nrow = i1 - i0;
-            T.n_slices = (uint16_t)((nrow + kTileSliceRows - 1) / kTileSliceRows);
-            T.row_base = (uint32_t)out.slot_row.size();
-            out.slot_row.resize(out.slot_row.size() + (size_t)T.n_slices * kTileSliceRows, -1);
-            T.fwd_off = (uint64_t)out.fwd.size() * 4;
-            T.bwd_off = (uint64_t)out.bwd.size() * 4;
-            T.coo_off = (uint32_t)out.coo.size();
-            out.n_fslices += T.n_slices;
-            // 3. forward slices (all of them first: the tile's forward block is contiguous).  Column j of a slice is 256
-            //    dwords; row p of the slice (p = position in sorted order) is field p/64 of the int4 of lane p%64: the 64
-            //    lanes of one E-step gather read 64 CONSECUTIVE sorted rows, i.e. mostly one family -- the same few
-            //    dictionary slots (LDS broadcast) or neighbouring ones (distinct banks) instead of a random spread
-            uint32_t zero_dword = zero_id | (zero_id << 10) | (zero_id << 20);
-            for (int s = 0; s < T.n_slices; s++) {
-                int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
-                int64_t k = 0;
-                for (int64_t i = a0; i < bnd; i++) { uint32_t r = perm[(size_t)i]; k = std::max<int64_t>(k, (int64_t)(row_ptr[r + 1] - row_ptr[r])); }
-                T.k[s] = (uint16_t)k;
-                size_t base = out.fwd.size();
-                out.fwd.resize(base + (size_t)k * kSliceDwords, zero_dword);
-                out.padded_slots += k * kTileSliceRows;
-                for (int64_t i = a0; i < bnd; i++) {
-                    uint32_t r = perm[(size_t)i];
-                    uint32_t in_slice = (uint32_t)(i - a0);
-                    out.slot_row[(size_t)T.row_base + (size_t)s * kTileSliceRows + in_slice] = (int64_t)r;
-                    uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-                    for (uint64_t q = b; q < e; q++) {
-                        int32_t d = loc[(size_t)col_idx[q]];
-                        const uint32_t fl = in_slice & 63u, fi = in_slice >> 6;      // lane, field: see slot numbering above
-                        uint32_t *dw = &out.fwd[base + (size_t)(q - b) * kSliceDwords + fl * 4 + fi / 3];
-                        const int sh = 10 * (int)(fi % 3);
-                        *dw = (*dw & ~(0x3FFu << sh)) | ((uint32_t)d << sh);
-                        if (d >= near_n) out.far_entries++;
-                    }
-                    out.tiled_entries += (int64_t)(e - b);
-                }
-            }
-            // 4. backward index of each slice: its (column, row) pairs sorted by column
-            for (int s = 0; s < T.n_slices; s++) {
-                int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
+            C.group_end = (uint32_t)out.groups.size();
+            out.chunks.push_back(C);
+            s = e;
+        }
+        if (out.far_tid.size() >= ((size_t)1 << 32)) return -1;
+    }
+    const auto tp4 = t_now();
+
+    // ---- P3: encode ----
+    // forward blocks, far blocks and row slots have known sizes (prefix sums over the slices): written in place by the pool.
+    // Backward blocks and COO lists are built per range of groups in private buffers and joined in order.
+    out.slices.resize((size_t)n_slices);
+    {
+        uint64_t fk = 0, fb = 0;
+        for (int64_t i = 0; i < n_slices; i++) {
+            SliceDesc &D = out.slices[(size_t)i];
+            std::memset(&D, 0, sizeof D);
+            const SliceTmp &S = st[(size_t)i];
+            D.fwd_kib = (uint32_t)fk; D.far_blk = (uint32_t)fb;
+            D.k = (uint16_t)S.k; D.nf = (uint16_t)((S.n_far + 63) / 64); D.n_rows = S.n_norm + S.n_far;
+            fk += S.k; fb += D.nf;
+            if (fk >= ((uint64_t)1 << 32)) return -1;
+        }
+        out.fwd.resize((size_t)fk * kSliceDwords);
+        out.far_blk_tid.assign((size_t)fb * 64, -1);
+        out.slot_row.resize((size_t)n_slices * kTileSliceRows);
+        out.padded_slots = (int64_t)fk * kTileSliceRows;
+    }
+    struct EncPart { u32_vec bwd; std::vector<uint32_t> coo; std::vector<std::pair<int32_t, uint32_t>> farp; int64_t tiled = 0, far = 0, exported = 0; };
+    const int64_t n_groups = (int64_t)out.groups.size();
+    const int n_parts = (int)std::max<int64_t>(1, std::min<int64_t>(n_groups, (int64_t)std::max(1, n_host) * 4));
+    std::vector<EncPart> parts((size_t)n_parts);
+    auto encode_groups = [&](int64_t gb, int64_t ge, EncPart &P) {
+        std::vector<int32_t> loc((size_t)n_tx, 0);
+        std::vector<uint32_t> pairs, sorted, ccount, fill, segs;
+        for (int64_t g = gb; g < ge; g++) {
+            const GroupDesc &G = out.groups[(size_t)g];
+            const int32_t lo = G.lo, near_n = G.near_n;
+            const int nd = (int)G.near_n + (int)G.far_n;
+            for (uint32_t i = 0; i < G.far_n; i++) loc[(size_t)out.far_tid[(size_t)G.far_off + i]] = near_n + (int32_t)i;
+            auto loc_of = [&](int32_t t) -> uint32_t { return (uint32_t)((t >= lo && t - lo < near_n) ? t - lo : loc[(size_t)t]); };
+            const uint32_t zero_id = (uint32_t)nd, pad_row = (uint32_t)kTileSliceRows;
+            const uint32_t zero_dword = zero_id | (zero_id << 10) | (zero_id << 20);
+            for (uint32_t si = G.slice_begin; si < G.slice_end; si++) {
+                SliceDesc &D = out.slices[(size_t)si];
+                const SliceTmp &S = st[(size_t)si];
+                uint32_t *fw = out.fwd.data() + (size_t)D.fwd_kib * kSliceDwords;
+                std::fill(fw, fw + (size_t)D.k * kSliceDwords, zero_dword);
+                int64_t *slots = out.slot_row.data() + (size_t)si * kTileSliceRows;
+                std::fill(slots, slots + kTileSliceRows, (int64_t)-1);
                 pairs.clear();
-                for (int64_t i = a0; i < bnd; i++) {
-                    uint32_t r = perm[(size_t)i];
-                    uint32_t in_slice = (uint32_t)(i - a0);
-                    for (uint64_t q = row_ptr[r]; q < row_ptr[r + 1]; q++) pairs.push_back(((uint32_t)loc[(size_t)col_idx[q]] << 16) | in_slice);
+                uint32_t n_norm = 0, n_far = 0;
+                for (int64_t i = S.begin; i < S.end; i++) {
+                    const uint32_t r = perm[(size_t)i];
+                    const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+                    const int64_t ex = export_index(r);
+                    const bool far_row = ex >= 0 && n_far < (uint32_t)(64 * kMaxFarBlocks);      // the rule of cut_slices
+                    uint32_t p;
+                    if (far_row) {
+                        const uint32_t blk = n_far / 64, ln = n_far % 64;
+                        p = (uint32_t)kTileSliceRows - 64 * (blk + 1) + ln;
+                        const int32_t ft = col_idx[b + (uint64_t)ex];
+                        out.far_blk_tid[((size_t)D.far_blk + blk) * 64 + ln] = ft;
+                        P.farp.emplace_back(ft, (uint32_t)(((size_t)D.far_blk + blk) * 64 + ln));
+                        n_far++; P.exported++;
+                    } else p = n_norm++;
+                    slots[p] = (int64_t)r;
+                    const uint32_t fl = p & 63u, fi = p >> 6;
+                    uint32_t c = 0;
+                    for (uint64_t q = b; q < e; q++) {
+                        if (far_row && (int64_t)(q - b) == ex) continue;
+                        const uint32_t d = loc_of(col_idx[q]);
+                        uint32_t *dw = &fw[(size_t)c * kSliceDwords + fl * 4 + fi / 3];
+                        const int sh = 10 * (int)(fi % 3);
+                        *dw = (*dw & ~(0x3FFu << sh)) | (d << sh);
+                        pairs.push_back((d << 16) | p);
+                        if ((int32_t)d >= near_n) P.far++;
+                        c++;
+                    }
+                    P.tiled += (int64_t)(e - b);
                 }
+                // backward index: (column, row) pairs sorted by column
                 ccount.assign((size_t)nd + 1, 0);
-                for (uint32_t p : pairs) ccount[(p >> 16) + 1]++;
+                for (uint32_t pr : pairs) ccount[(pr >> 16) + 1]++;
                 for (int d = 0; d < nd; d++) ccount[(size_t)d + 1] += ccount[(size_t)d];
                 sorted.resize(pairs.size());
                 fill.assign(ccount.begin(), ccount.end() - 1);
-                for (uint32_t p : pairs) sorted[fill[p >> 16]++] = p;
+                for (uint32_t pr : pairs) sorted[fill[pr >> 16]++] = pr;
                 segs.clear();
-                size_t coo_before = out.coo.size();
+                const size_t coo_before = P.coo.size();
                 for (int d = 0; d < nd; d++) {
-                    uint32_t b = ccount[(size_t)d], e = ccount[(size_t)d + 1];
+                    const uint32_t b = ccount[(size_t)d], e = ccount[(size_t)d + 1];
                     if (e - b < (uint32_t)dense_min) {
-                        for (uint32_t q = b; q < e; q++) out.coo.push_back(((uint32_t)d << 16) | (sorted[q] & 0xFFFF));
+                        for (uint32_t q = b; q < e; q++) P.coo.push_back(((uint32_t)d << 16) | (sorted[q] & 0xFFFF));
                         continue;
                     }
                     for (uint32_t q = b; q < e; q += kSegRows) {
@@ -502,105 +647,81 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                         segs.insert(segs.end(), seg, seg + 4);
                     }
                 }
-                T.coo_n[s] = (uint16_t)(out.coo.size() - coo_before);
-                out.coo_entries += T.coo_n[s];
+                D.coo_off = (uint32_t)coo_before;                         // part-local; rebased when the parts are joined
+                D.coo_n = (uint16_t)(P.coo.size() - coo_before);
                 const int64_t nseg = (int64_t)segs.size() / 4;
                 const int m = (int)((nseg + 63) / 64);
-                T.m[s] = (uint16_t)m;
-                size_t base = out.bwd.size();
+                D.m = (uint16_t)m;
+                D.bwd_kib = (uint32_t)(P.bwd.size() / kSliceDwords);      // part-local
                 uint32_t empty[4] = {0, 0, 0, 0};                          // unused segment: zero column, padding rows
                 pack10(empty, 0, zero_id);
                 for (int j = 1; j < 12; j++) pack10(empty, j, pad_row);
-                out.bwd.resize(base + (size_t)m * 64 * 4, 0u);
-                for (int64_t g = 0; g < (int64_t)m * 64; g++) {
-                    // logical segment g -> lane g / m, unit g % m ; physical int4 index (unit*64 + lane)
-                    int64_t lane = g / m, unit = g % m;
-                    size_t u0 = base + (size_t)((unit * 64 + lane) * 4);
-                    const uint32_t *src = g < nseg ? &segs[(size_t)g * 4] : empty;
-                    for (int w = 0; w < 4; w++) out.bwd[u0 + (size_t)w] = src[w];
+                const size_t base = P.bwd.size();
+                P.bwd.resize(base + (size_t)m * 64 * 4);
+                for (int64_t gg = 0; gg < (int64_t)m * 64; gg++) {
+                    // logical segment gg -> lane gg / m, unit gg % m ; physical int4 index (unit*64 + lane)
+                    const int64_t lane = gg / m, unit = gg % m;
+                    const size_t u0 = base + (size_t)((unit * 64 + lane) * 4);
+                    const uint32_t *src = gg < nseg ? &segs[(size_t)gg * 4] : empty;
+                    for (int w = 0; w < 4; w++) P.bwd[u0 + (size_t)w] = src[w];
                 }
             }
-            out.tiles.push_back(T);
-            for (int32_t t : distinct) stamp[(size_t)t] = -1;
-            tile_id++;
-            i0 = i1;
         }
-        return 0;
     };
     {
-        int64_t frag_rows = kFragRows;
-        if (const char *e = getenv("EMSAR_HIP_FRAG_ROWS")) { long long v = atoll(e); if (v >= kTileRows) frag_rows = v; }   // tests: many fragments on small inputs
-        const int64_t n_frag = std::max<int64_t>(1, (n_act + frag_rows - 1) / frag_rows);
-        std::vector<TiledLayout> frag((size_t)n_frag);
-        std::vector<int> frc((size_t)n_frag, 0);
-        unsigned hw = std::thread::hardware_concurrency();
-        int nthr = (int)std::min<int64_t>(n_frag, hw ? std::min(hw, 16u) : 1u);
-        if (const char *e = getenv("EMSAR_HOST_THREADS")) { int v = atoi(e); if (v >= 1) nthr = (int)std::min<int64_t>(n_frag, v); }
-        std::atomic<int64_t> next{0};
-        auto worker = [&]() {
+        std::atomic<int> next{0};
+        run_on_threads((int)std::min<int64_t>(n_parts, std::max(1, n_host)), [&](int) {
             for (;;) {
-                const int64_t g = next.fetch_add(1);
-                if (g >= n_frag) break;
-                frc[(size_t)g] = form_tiles(g * frag_rows, std::min(n_act, (g + 1) * frag_rows), frag[(size_t)g]);
+                const int pi = next.fetch_add(1);
+                if (pi >= n_parts) break;
+                encode_groups(n_groups * pi / n_parts, n_groups * (pi + 1) / n_parts, parts[(size_t)pi]);
             }
-        };
-        run_on_threads(nthr, [&](int) { worker(); });
-        for (int64_t g = 0; g < n_frag; g++) if (frc[(size_t)g] != 0) return frc[(size_t)g];
-        const auto tp3 = t_now();
-        if (dbg_t) fprintf(stderr, "build_tiled: classify %.0f ms, sort %.0f ms, tiles %.0f ms on %d thread(s)\n", t_ms(tp0, tp1), t_ms(tp1, tp2), t_ms(tp2, tp3), nthr);
-        // concatenate: descriptors, COO pairs and far lists here (small), the three big arrays by the pool, each fragment
-        // into its own range of the final arrays
-        std::vector<size_t> slot_b((size_t)n_frag + 1, 0), fwd_b((size_t)n_frag + 1, 0), bwd_b((size_t)n_frag + 1, 0);
-        {
-            size_t nt_ = 0, nc_ = 0, nfar_ = 0;
-            for (int64_t g = 0; g < n_frag; g++) {
-                const TiledLayout &F = frag[(size_t)g];
-                nt_ += F.tiles.size(); nc_ += F.coo.size(); nfar_ += F.far_tid.size();
-                slot_b[(size_t)g + 1] = slot_b[(size_t)g] + F.slot_row.size();
-                fwd_b[(size_t)g + 1] = fwd_b[(size_t)g] + F.fwd.size();
-                bwd_b[(size_t)g + 1] = bwd_b[(size_t)g] + F.bwd.size();
-            }
-            if (slot_b[(size_t)n_frag] >= ((size_t)1 << 32)) return -1;
-            if (nc_ >= ((size_t)1 << 32) || nfar_ >= ((size_t)1 << 32)) return -1;     // Tile::coo_off / far_off are 32-bit
-            out.tiles.reserve(nt_); out.coo.reserve(nc_); out.far_tid.reserve(nfar_);
-            out.slot_row.resize(slot_b[(size_t)n_frag]); out.fwd.resize(fwd_b[(size_t)n_frag]); out.bwd.resize(bwd_b[(size_t)n_frag]);
-        }
-        for (int64_t g = 0; g < n_frag; g++) {
-            TiledLayout &F = frag[(size_t)g];
-            const uint32_t far_b = (uint32_t)out.far_tid.size(), coo_b = (uint32_t)out.coo.size();
-            for (Tile t : F.tiles) {
-                t.fwd_off += (uint64_t)fwd_b[(size_t)g] * 4; t.bwd_off += (uint64_t)bwd_b[(size_t)g] * 4;
-                t.row_base += (uint32_t)slot_b[(size_t)g]; t.far_off += far_b; t.coo_off += coo_b;
-                out.tiles.push_back(t);
-            }
-            out.coo.insert(out.coo.end(), F.coo.begin(), F.coo.end());
-            out.far_tid.insert(out.far_tid.end(), F.far_tid.begin(), F.far_tid.end());
-            out.tiled_entries += F.tiled_entries; out.far_entries += F.far_entries; out.coo_entries += F.coo_entries;
-            out.n_fslices += F.n_fslices; out.padded_slots += F.padded_slots;
-        }
-        next.store(0);
-        auto copier = [&]() {
-            for (;;) {
-                const int64_t g = next.fetch_add(1);
-                if (g >= n_frag) break;
-                TiledLayout &F = frag[(size_t)g];
-                if (!F.slot_row.empty()) memcpy(out.slot_row.data() + slot_b[(size_t)g], F.slot_row.data(), F.slot_row.size() * sizeof(int64_t));
-                if (!F.fwd.empty()) memcpy(out.fwd.data() + fwd_b[(size_t)g], F.fwd.data(), F.fwd.size() * 4);
-                if (!F.bwd.empty()) memcpy(out.bwd.data() + bwd_b[(size_t)g], F.bwd.data(), F.bwd.size() * 4);
-                F = TiledLayout();
-            }
-        };
-        run_on_threads(nthr, [&](int) { copier(); });
+        });
     }
-    // Largest tiles first: they start while the grid is full, the small ones fill the tail.
-    auto work = [](const Tile &t) {
-        int64_t w = 0;
-        for (int s = 0; s < t.n_slices; s++) w += (int64_t)t.k[s] * kTileSliceRows + (int64_t)t.m[s] * 64 * 12 + t.coo_n[s] * 2;
-        return w;
-    };
-    std::stable_sort(out.tiles.begin(), out.tiles.end(), [&](const Tile &a, const Tile &b) { return work(a) > work(b); });
-    if (dbg_t) fprintf(stderr, "build_tiled: total %.0f ms\n", t_ms(tp0, t_now()));
-    return check_tiled_extents(out);       // O(tiles): no descriptor may point outside the arrays that are uploaded next
+    // join the parts: rebase the part-local backward / COO offsets, concatenate
+    {
+        std::vector<size_t> bb((size_t)n_parts + 1, 0), cb((size_t)n_parts + 1, 0), fp((size_t)n_parts + 1, 0);
+        for (int pi = 0; pi < n_parts; pi++) {
+            bb[(size_t)pi + 1] = bb[(size_t)pi] + parts[(size_t)pi].bwd.size();
+            cb[(size_t)pi + 1] = cb[(size_t)pi] + parts[(size_t)pi].coo.size();
+            fp[(size_t)pi + 1] = fp[(size_t)pi] + parts[(size_t)pi].farp.size();
+        }
+        if (bb[(size_t)n_parts] / kSliceDwords >= ((size_t)1 << 32) || cb[(size_t)n_parts] >= ((size_t)1 << 32) || fp[(size_t)n_parts] >= ((size_t)1 << 32)) return -1;
+        out.bwd.resize(bb[(size_t)n_parts]);
+        out.coo.resize(cb[(size_t)n_parts]);
+        for (int pi = 0; pi < n_parts; pi++) {
+            const int64_t gb = n_groups * pi / n_parts, ge = n_groups * (pi + 1) / n_parts;
+            if (gb < ge)
+                for (uint32_t si = out.groups[(size_t)gb].slice_begin; si < out.groups[(size_t)ge - 1].slice_end; si++) {
+                    out.slices[(size_t)si].bwd_kib += (uint32_t)(bb[(size_t)pi] / kSliceDwords);
+                    out.slices[(size_t)si].coo_off += (uint32_t)cb[(size_t)pi];
+                }
+            out.tiled_entries += parts[(size_t)pi].tiled; out.far_entries += parts[(size_t)pi].far; out.exported_entries += parts[(size_t)pi].exported;
+        }
+        std::atomic<int> next{0};
+        run_on_threads((int)std::min<int64_t>(n_parts, std::max(1, n_host)), [&](int) {
+            for (;;) {
+                const int pi = next.fetch_add(1);
+                if (pi >= n_parts) break;
+                EncPart &P = parts[(size_t)pi];
+                if (!P.bwd.empty()) memcpy(out.bwd.data() + bb[(size_t)pi], P.bwd.data(), P.bwd.size() * 4);
+                if (!P.coo.empty()) memcpy(out.coo.data() + cb[(size_t)pi], P.coo.data(), P.coo.size() * 4);
+                u32_vec().swap(P.bwd); std::vector<uint32_t>().swap(P.coo);
+            }
+        });
+        out.coo_entries = (int64_t)out.coo.size();
+        // exported entries by transcript: the parts in order are in slice order, a stable counting sort by tid keeps it
+        out.far_ptr.assign((size_t)n_tx + 1, 0);
+        for (const auto &P : parts) for (const auto &fe : P.farp) out.far_ptr[(size_t)fe.first + 1]++;
+        for (int32_t t = 0; t < n_tx; t++) out.far_ptr[(size_t)t + 1] += out.far_ptr[(size_t)t];
+        out.far_pos.resize(fp[(size_t)n_parts]);
+        std::vector<uint32_t> fillp(out.far_ptr.begin(), out.far_ptr.end() - 1);
+        for (const auto &P : parts) for (const auto &fe : P.farp) out.far_pos[fillp[(size_t)fe.first]++] = fe.second;
+    }
+    if (dbg_t) fprintf(stderr, "build_tiled: classify %.0f ms, sort %.0f ms, slices %.0f ms, groups %.0f ms, encode %.0f ms on %d thread(s); %lld slices, %lld groups, %lld chunks, %lld exported far entries, %lld explicit\n",
+                       t_ms(tp0, tp1), t_ms(tp1, tp2), t_ms(tp2, tp3), t_ms(tp3, tp4), t_ms(tp4, t_now()), n_host, (long long)n_slices, (long long)n_groups,
+                       (long long)out.chunks.size(), (long long)out.exported_entries, (long long)out.far_entries);
+    return check_tiled_extents(out);       // O(slices): no descriptor may point outside the arrays that are uploaded next
 }
 
 // Decode and compare with the input (host self-check, used by the CPU tests). 0 = identical.
@@ -621,67 +742,92 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
         if (x != y) return -2;
         seen[r] = 1;
     }
+    // exported entries: far_ptr / far_pos is the transpose of the far blocks
+    {
+        std::vector<uint8_t> hit(L.far_blk_tid.size(), 0);
+        for (int32_t t = 0; t < L.n_tx; t++)
+            for (uint32_t q = L.far_ptr[(size_t)t]; q < L.far_ptr[(size_t)t + 1]; q++) {
+                const uint32_t pos = L.far_pos[q];
+                if (pos >= L.far_blk_tid.size() || hit[pos] || L.far_blk_tid[pos] != t) return -11;
+                hit[pos] = 1;
+            }
+        for (size_t i = 0; i < hit.size(); i++) if (!hit[i] && L.far_blk_tid[i] >= 0) return -11;
+    }
     std::vector<int32_t> a, b;
     std::vector<uint32_t> pf, pb;
-    for (const Tile &T : L.tiles) {
-        const int nd = T.near_n + T.far_n;
-        if (nd > kTileDict || T.n_slices > kTileSlices || T.row_base % kTileSliceRows) return -3;
-        auto tid_of = [&](int d) { return d < T.near_n ? T.lo + d : L.far_tid[(size_t)T.far_off + (size_t)(d - T.near_n)]; };
-        size_t foff = (size_t)(T.fwd_off / 4), boff = (size_t)(T.bwd_off / 4), coff = T.coo_off;
-        for (int s = 0; s < T.n_slices; s++) {
-            pf.clear(); pb.clear();
-            for (int i = 0; i < kTileSliceRows; i++) {
-                int64_t r = L.slot_row[(size_t)T.row_base + (size_t)s * kTileSliceRows + (size_t)i];
-                a.clear();
-                for (int j = 0; j < T.k[s]; j++) {
+    std::vector<uint8_t> slice_seen(L.slices.size(), 0);
+    for (size_t ci = 0; ci < L.chunks.size(); ci++) {
+        if (L.chunks[ci].group_begin != (ci ? L.chunks[ci - 1].group_end : 0u)) return -12;          // chunks tile the groups
+        for (uint32_t g = L.chunks[ci].group_begin; g < L.chunks[ci].group_end; g++) {
+            const GroupDesc &G = L.groups[g];
+            if (G.slice_begin != (g ? L.groups[g - 1].slice_end : 0u)) return -12;                     // groups tile the slices
+            const int nd = G.near_n + G.far_n;
+            auto tid_of = [&](int d) { return d < G.near_n ? G.lo + d : L.far_tid[(size_t)G.far_off + (size_t)(d - G.near_n)]; };
+            for (uint32_t si = G.slice_begin; si < G.slice_end; si++) {
+                const SliceDesc &D = L.slices[si];
+                slice_seen[si] = 1;
+                pf.clear(); pb.clear();
+                const size_t foff = (size_t)D.fwd_kib * kSliceDwords;
+                uint32_t rows_found = 0;
+                for (int i = 0; i < kTileSliceRows; i++) {
+                    const int64_t r = L.slot_row[(size_t)si * kTileSliceRows + (size_t)i];
+                    a.clear();
                     const int fl = i & 63, fi = i >> 6;
-                    int d = (int)((L.fwd[foff + (size_t)j * kSliceDwords + (size_t)(fl * 4 + fi / 3)] >> (10 * (fi % 3))) & 0x3FFu);
-                    if (d > nd) return -4;
-                    if (d == nd) continue;                        // zero slot = padding
-                    a.push_back(tid_of(d));
-                    pf.push_back(((uint32_t)d << 16) | (uint32_t)i);
-                }
-                if (r < 0) { if (!a.empty()) return -5; continue; }
-                if (L.merged) {                                   // every member row has this tid multiset
-                    if (L.mem_ptr[(size_t)r + 1] == L.mem_ptr[(size_t)r]) return -6;
-                    for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) {
-                        uint32_t o = L.mem_row[(size_t)q];
-                        if (seen[o]) return -6;
-                        seen[o] = 1;
-                        b.assign(col_idx + row_ptr[o], col_idx + row_ptr[o + 1]);
-                        std::sort(b.begin(), b.end());
-                        if (a != b) return -7;
+                    for (int j = 0; j < D.k; j++) {
+                        const int d = (int)((L.fwd[foff + (size_t)j * kSliceDwords + (size_t)(fl * 4 + fi / 3)] >> (10 * (fi % 3))) & 0x3FFu);
+                        if (d > nd) return -4;
+                        if (d == nd) continue;                        // zero slot = padding
+                        a.push_back(tid_of(d));
+                        pf.push_back(((uint32_t)d << 16) | (uint32_t)i);
                     }
-                    continue;
+                    // the exported entry of a row in a far field
+                    const int blk = 11 - fi;
+                    if (blk < (int)D.nf) {
+                        const int32_t ft = L.far_blk_tid[((size_t)D.far_blk + (size_t)blk) * 64 + (size_t)fl];
+                        if (ft >= 0) { if (r < 0) return -5; a.push_back(ft); }
+                    }
+                    if (r < 0) { if (!a.empty()) return -5; continue; }
+                    rows_found++;
+                    std::sort(a.begin(), a.end());
+                    if (L.merged) {                                   // every member row has this tid multiset
+                        if (L.mem_ptr[(size_t)r + 1] == L.mem_ptr[(size_t)r]) return -6;
+                        for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) {
+                            uint32_t o = L.mem_row[(size_t)q];
+                            if (seen[o]) return -6;
+                            seen[o] = 1;
+                            b.assign(col_idx + row_ptr[o], col_idx + row_ptr[o + 1]);
+                            std::sort(b.begin(), b.end());
+                            if (a != b) return -7;
+                        }
+                        continue;
+                    }
+                    if (seen[(size_t)r]) return -6;
+                    seen[(size_t)r] = 1;
+                    b.assign(col_idx + row_ptr[r], col_idx + row_ptr[r + 1]);
+                    std::sort(b.begin(), b.end());
+                    if (a != b) return -7;
                 }
-                if (seen[(size_t)r]) return -6;
-                seen[(size_t)r] = 1;
-                b.assign(col_idx + row_ptr[r], col_idx + row_ptr[r + 1]);
-                if (a != b) return -7;
-            }
-            foff += (size_t)T.k[s] * kSliceDwords;
-            const int m = T.m[s];
-            for (int64_t g = 0; g < (int64_t)m * 64; g++) {
-                int64_t lane = g / m, unit = g % m;
-                const uint32_t *q = &L.bwd[boff + (size_t)((unit * 64 + lane) * 4)];
-                uint32_t d = unpack10(q, 0);
-                for (int w = 1; w < 12; w++) {
-                    uint32_t rl = unpack10(q, w);
-                    if (rl == (uint32_t)kTileSliceRows) continue;
-                    if (rl > (uint32_t)kTileSliceRows || d >= (uint32_t)nd) return -8;
-                    pb.push_back((d << 16) | rl);
+                if (rows_found != D.n_rows) return -5;
+                const size_t boff = (size_t)D.bwd_kib * kSliceDwords;
+                const int m = D.m;
+                for (int64_t gg = 0; gg < (int64_t)m * 64; gg++) {
+                    const int64_t lane = gg / m, unit = gg % m;
+                    const uint32_t *q = &L.bwd[boff + (size_t)((unit * 64 + lane) * 4)];
+                    const uint32_t d = unpack10(q, 0);
+                    for (int w = 1; w < 12; w++) {
+                        const uint32_t rl = unpack10(q, w);
+                        if (rl == (uint32_t)kTileSliceRows) continue;
+                        if (rl > (uint32_t)kTileSliceRows || d >= (uint32_t)nd) return -8;
+                        pb.push_back((d << 16) | rl);
+                    }
                 }
+                for (uint32_t q = 0; q < D.coo_n; q++) pb.push_back(L.coo[(size_t)D.coo_off + q]);
+                std::sort(pf.begin(), pf.end()); std::sort(pb.begin(), pb.end());
+                if (pf != pb) return -9;                                // the backward index is the transpose of the forward one
             }
-            boff += (size_t)m * 64 * 4;
-            for (uint32_t q = 0; q < T.coo_n[s]; q++) {
-                uint32_t p = L.coo[coff + q];
-                pb.push_back(p);
-            }
-            coff += T.coo_n[s];
-            std::sort(pf.begin(), pf.end()); std::sort(pb.begin(), pb.end());
-            if (pf != pb) return -9;                                // the backward index is the transpose of the forward one
         }
     }
+    for (uint8_t x : slice_seen) if (!x) return -12;
     for (int64_t r = 0; r < L.n_rows; r++)
         if (!seen[(size_t)r] && row_ptr[r + 1] != row_ptr[r]) return -10;
     return 0;

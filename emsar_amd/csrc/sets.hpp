@@ -37,10 +37,10 @@ constexpr int kSetThreads[kSetClasses] = {64, 256, 512};
 constexpr size_t kSetLdsCap[kSetClasses] = {6 * 1024, 48 * 1024, 156 * 1024};
 constexpr int kSetRedDoubles = 64;   // LDS scratch of the workgroup reductions (4 values x 16 waves)
 
-// bytes of LDS one resident set needs: 5 transcript vectors (A, B, C, den, u), 2 row vectors (w, R), the
-// reduction scratch and the four 16-bit index arrays
+// bytes of LDS one resident set needs: 8 transcript vectors (A, B, C, den, u and the Newton step's z, Hp, 1/diag), 3 row
+// vectors (w, R, R/S^2), the reduction scratch and the four 16-bit index arrays
 inline size_t set_lds_bytes(size_t n_t, size_t n_r, size_t nnz) {
-    size_t b = 8 * (5 * n_t + 2 * n_r + (size_t)kSetRedDoubles) + 2 * ((n_r + 1) + (n_t + 1) + 2 * nnz);
+    size_t b = 8 * (8 * n_t + 3 * n_r + (size_t)kSetRedDoubles) + 2 * ((n_r + 1) + (n_t + 1) + 2 * nnz);
     return (b + 15) & ~(size_t)15;
 }
 

@@ -6,10 +6,11 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_PKG, "libemsar_hip.so")
+# EMSAR_HIP_LIB: experiment hook -- another build of the same library (timing-only ablations, compile-time variants)
+_LIB_PATH = os.environ.get("EMSAR_HIP_LIB") or os.path.join(_PKG, "libemsar_hip.so")
 _lib = None
 
-LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_WINDOWED, LAYOUT_TILED = 0, 1, 2, 3
+LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_TILED = 0, 1, 3
 FLAG_MERGE_ROWS = 0x100
 
 # every symbol include/emsar_hip.h declares (tests check that the library exports exactly these)
@@ -17,7 +18,7 @@ SYMBOLS = [
     "emsar_hip_create", "emsar_hip_destroy", "emsar_hip_strerror", "emsar_hip_last_error",
     "emsar_hip_upload_structure", "emsar_hip_upload_sample", "emsar_hip_solve",
     "emsar_hip_reset_theta", "emsar_hip_set_theta", "emsar_hip_get_theta", "emsar_hip_run_passes",
-    "emsar_hip_ieuma", "emsar_hip_normalise", "emsar_hip_get_info", "emsar_hip_layout_selfcheck",
+    "emsar_hip_ieuma", "emsar_hip_normalise", "emsar_hip_get_info",
     "emsar_hip_layout_selfcheck_tiled", "emsar_hip_sets_selfcheck", "emsar_hip_upload_euma", "emsar_hip_adj_euma", "emsar_hip_collapse_rows",
 ]
 
@@ -30,7 +31,8 @@ class EmsarHipError(RuntimeError):
 
 class EmParams(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("accel", C.c_int32), ("tol", C.c_double), ("abs_floor", C.c_double),
-                ("check_every", C.c_int32), ("set_mode", C.c_int32), ("count_floor", C.c_double), ("zero_cut", C.c_double), ("abs_step", C.c_double)]
+                ("check_every", C.c_int32), ("set_mode", C.c_int32), ("count_floor", C.c_double), ("zero_cut", C.c_double), ("abs_step", C.c_double),
+                ("newton_after", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class EmStats(C.Structure):
@@ -57,7 +59,7 @@ class Info(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("nnz", C.c_int64), ("n_tx", C.c_int32), ("layout", C.c_int32),
                 ("n_chunks", C.c_int64), ("n_slices", C.c_int64), ("padded_entries", C.c_int64),
                 ("far_entries", C.c_int64), ("window", C.c_int32), ("device_id", C.c_int32),
-                ("bytes_per_pass", C.c_int64), ("stored_bytes_per_pass", C.c_int64)]
+                ("bytes_per_pass", C.c_int64), ("stored_bytes_per_pass", C.c_int64), ("n_groups", C.c_int64), ("exported_entries", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -89,7 +91,6 @@ def load_library():
     L.emsar_hip_ieuma.argtypes = [vp, f64p, f64p]
     L.emsar_hip_normalise.argtypes = [vp, f64p, f64p, C.c_int64, f64p, f64p, i32p]
     L.emsar_hip_get_info.argtypes = [vp, C.POINTER(Info)]
-    L.emsar_hip_layout_selfcheck.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int32, C.c_int64, C.POINTER(Info)]
     L.emsar_hip_layout_selfcheck_tiled.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int, C.POINTER(Info)]
     L.emsar_hip_collapse_rows.argtypes = [vp, C.c_int64, C.c_int32, u64p, i32p, i32p, C.POINTER(C.c_int64), u64p, i32p, i32p, i32p,
                                           C.POINTER(CollapseStats)]
@@ -115,18 +116,6 @@ def _arr(a, dt):
     return None if a is None else np.ascontiguousarray(a, dtype=dt)
 
 
-def layout_selfcheck(n_tx, row_ptr, col_idx, window=0, chunk_entries=0):
-    """Host-only: build + decode the WINDOWED layout (no GPU needed).  Returns its statistics."""
-    L = load_library()
-    row_ptr, col_idx = _arr(row_ptr, np.uint64), _arr(col_idx, np.int32)
-    info = Info()
-    rc = L.emsar_hip_layout_selfcheck(len(row_ptr) - 1, n_tx, _p(row_ptr, C.c_uint64), _p(col_idx, C.c_int32),
-                                      window, chunk_entries, C.byref(info))
-    if rc != 0:
-        raise EmsarHipError(rc, "layout_selfcheck")
-    return info.as_dict()
-
-
 def sets_selfcheck(n_tx, row_ptr, col_idx, row_weight=None):
     """Host-only: find + pack the connected sets for the set-resident solver and check the records (no GPU needed)."""
     L = load_library()
@@ -144,7 +133,7 @@ def sets_selfcheck(n_tx, row_ptr, col_idx, row_weight=None):
 
 
 def layout_selfcheck_tiled(n_tx, row_ptr, col_idx, merge_rows=False):
-    """Host-only: build + decode the TILED layout (no GPU needed).  Returns its statistics."""
+    """Host-only: build the TILED layout, check its descriptors and decode it again (no GPU needed).  Returns its statistics."""
     L = load_library()
     row_ptr, col_idx = _arr(row_ptr, np.uint64), _arr(col_idx, np.int32)
     info = Info()
@@ -205,9 +194,11 @@ class EmsarHip:
         self._chk(self._L.emsar_hip_upload_sample(self._h, _p(w, C.c_int32), _p(e, C.c_double), _p(d, C.c_double)),
                   "upload_sample")
 
-    def solve(self, max_iter=100000, accel=1, tol=1e-10, abs_floor=1e-6, check_every=8, count_floor=0.0, set_mode=0, zero_cut=0.0, abs_step=0.0):
-        """set_mode 0: connected sets that fit a CU's LDS are solved by one workgroup each; 1: streaming passes only."""
-        p = EmParams(max_iter, accel, tol, abs_floor, check_every, set_mode, count_floor, zero_cut, abs_step)
+    def solve(self, max_iter=100000, accel=1, tol=1e-10, abs_floor=1e-6, check_every=8, count_floor=0.0, set_mode=0, zero_cut=0.0, abs_step=0.0,
+              newton_after=0):
+        """set_mode 0: connected sets that fit a CU's LDS are solved by one workgroup each; 1: streaming passes only.
+        newton_after: resident sets get projected-Newton steps once they have used this many passes (0 = 60, < 0 = never)."""
+        p = EmParams(max_iter, accel, tol, abs_floor, check_every, set_mode, count_floor, zero_cut, abs_step, newton_after, 0)
         st = EmStats()
         out = np.zeros(self.n_tx)
         self._chk(self._L.emsar_hip_solve(self._h, C.byref(p), _p(out, C.c_double), C.byref(st)), "solve")

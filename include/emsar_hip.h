@@ -42,11 +42,14 @@ typedef enum {
 typedef enum {
     EMSAR_LAYOUT_AUTO = 0,   /* TILED when it applies, else CSR */
     EMSAR_LAYOUT_CSR = 1,    /* rows as given; lane-per-row walk, FP64 atomics straight to HBM/L2 */
-    EMSAR_LAYOUT_WINDOWED = 2, /* rows bucketed by smallest tid and length into 256-row column-major slices;
-                                 theta / accumulator windows staged in LDS, LDS atomics for the M-step */
-    EMSAR_LAYOUT_TILED = 3    /* tiles of <= 4096 rows with a chunk-local dictionary: 16-bit operands, forward index
-                                 for the E-step and transposed index for the M-step (no atomics on the hot path);
-                                 single-tid rows folded into a per-transcript count */
+    /* 2 was the WINDOWED layout of round 1 (4x slower than TILED, removed) */
+    EMSAR_LAYOUT_TILED = 3    /* rows sorted by (block of their median tid, length, median tid) and cut into slices of <= 768 rows,
+                                 one wavefront each: 10-bit operands (three to a dword), forward index for the E-step and a
+                                 per-slice transposed index for the M-step (no atomics in the inner loops); consecutive slices
+                                 share a dictionary of <= 959 transcripts in LDS (a group), a workgroup owns a chunk of equal
+                                 work; entries far from their row's median are exported to per-slice far blocks and summed by
+                                 the update kernel; single-tid rows folded into a per-transcript count; rows longer than 768
+                                 tids go to a small CSR of their own */
 } emsar_hip_layout;
 
 /* OR-ed into the layout argument of emsar_hip_upload_structure (TILED only): store rows with the same tid multiset
@@ -81,6 +84,10 @@ typedef struct {
                              pass K is at most ~a*K, so the rule bounds the remaining drift by abs_step * 2e5 at every K --
                              2e-8 FPKM, a fiftieth of the .fpkm print quantum, for 1e-13 -- while the relative rule at 1e-10
                              keeps such components going for 10^5 passes.  <= 0 = off. */
+    int32_t newton_after; /* set_mode 0, resident sets: a set that has not converged after this many passes gets one safeguarded
+                             projected-Newton step (direction by matrix-free conjugate gradients, accepted only if F does not
+                             fall) after every SQUAREM cycle.  0 -> 60, < 0 = never (EM / SQUAREM only). */
+    int32_t reserved0;
 } emsar_em_params;
 
 typedef struct {
@@ -179,22 +186,22 @@ typedef struct {
     int64_t n_rows, nnz;
     int32_t n_tx;
     int32_t layout;            /* layout in use (flags included) */
-    int64_t n_chunks;          /* WINDOWED: chunks / TILED: tiles (one workgroup each) */
-    int64_t n_slices;          /* WINDOWED: 256-row slices / TILED: 512-row forward slices */
+    int64_t n_chunks;          /* TILED: chunks (one workgroup each) */
+    int64_t n_slices;          /* TILED: 768-row slices (one wavefront at a time) */
     int64_t padded_entries;    /* stored forward slots incl. padding */
-    int64_t far_entries;       /* entries outside their chunk's contiguous tid range */
-    int32_t window;            /* transcripts per LDS window / dictionary */
+    int64_t far_entries;       /* entries outside their group's contiguous tid range (exported ones included) */
+    int32_t window;            /* transcripts per dictionary */
     int32_t device_id;
     int64_t bytes_per_pass;        /* SURVEY.md 8d formula */
     int64_t stored_bytes_per_pass; /* what the layout streams */
+    int64_t n_groups;          /* TILED: groups of slices that share a dictionary */
+    int64_t exported_entries;  /* TILED: far entries served through the far blocks instead of a dictionary slot */
 } emsar_hip_info;
 int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *out);
 
-/* Host-only diagnostic (no HIP call, works without a GPU): build the WINDOWED layout for a CSR, decode it
- * again and check that it stores exactly the input rows.  window / chunk_entries <= 0 select the defaults. */
-int emsar_hip_layout_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
-                               int32_t window, int64_t chunk_entries, emsar_hip_info *info_out);
-/* The same for the TILED layout (forward index, transposed index, dictionaries, folded and leftover rows). */
+/* Host-only diagnostic (no HIP call, works without a GPU): build the TILED layout for a CSR (forward index, transposed index,
+ * dictionaries, far blocks, folded and leftover rows), check every descriptor against the arrays it indexes, decode the layout
+ * again and check that it stores exactly the input rows. */
 int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                                      int merge_rows, emsar_hip_info *info_out);
 

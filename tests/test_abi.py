@@ -33,10 +33,10 @@ def test_header_symbols_are_exported(lib):
 
 def test_struct_sizes_match_header(lib):
     # plain C layout, no padding surprises between the header and the ctypes mirror
-    assert C.sizeof(H.EmParams) == 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8
+    assert C.sizeof(H.EmParams) == 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 4 + 4
     assert C.sizeof(H.EmStats) == 4 + 4 + 8 * 4 + 8 * 2 + 4 * 4 + 8 * 3
     assert C.sizeof(H.SetsInfo) == 8 * 13
-    assert C.sizeof(H.Info) == 8 * 2 + 4 * 2 + 8 * 4 + 4 * 2 + 8 * 2
+    assert C.sizeof(H.Info) == 8 * 2 + 4 * 2 + 8 * 4 + 4 * 2 + 8 * 4
 
 
 def test_strerror(lib):
@@ -60,37 +60,47 @@ def test_null_and_malformed_arguments(lib):
     rp = np.array([0, 2, 1], dtype=np.uint64)           # not monotone
     ci = np.array([0, 1], dtype=np.int32)
     with pytest.raises(emsar_amd.EmsarHipError):
-        emsar_amd.layout_selfcheck(4, rp, ci)
+        emsar_amd.layout_selfcheck_tiled(4, rp, ci)
     rp = np.array([0, 2], dtype=np.uint64)
     for bad in ([0, 4], [-1, 0]):                        # tid outside [0, n_tx)
         with pytest.raises(emsar_amd.EmsarHipError):
-            emsar_amd.layout_selfcheck(4, rp, np.array(bad, dtype=np.int32))
+            emsar_amd.layout_selfcheck_tiled(4, rp, np.array(bad, dtype=np.int32))
 
 
-@pytest.mark.parametrize("window,chunk", [(0, 0), (256, 1024), (1024, 4096)])
-def test_layout_roundtrip_synthetic(lib, window, chunk):
+@pytest.mark.parametrize("chunks,export", [(None, "1"), ("7", "1"), ("64", "0")])
+def test_layout_roundtrip_synthetic(lib, chunks, export, monkeypatch):
+    """The TILED builder on a matrix with cross-family reads: descriptors inside their arrays, decoded rows = input rows,
+    for the default chunk count, a handful of chunks, and with the far-entry export switched off."""
+    if chunks:
+        monkeypatch.setenv("EMSAR_HIP_CHUNKS", chunks)
+    monkeypatch.setenv("EMSAR_HIP_FAR_EXPORT", export)
     m = synth.make_matrix(n_tx=6000, n_reads=40000, law="human", xfam=0.05, seed=9)
-    info = emsar_amd.layout_selfcheck(m["n_tx"], m["row_ptr"], m["col_idx"], window, chunk)
+    info = emsar_amd.layout_selfcheck_tiled(m["n_tx"], m["row_ptr"], m["col_idx"])
     nnz = len(m["col_idx"])
-    assert info["nnz"] == nnz and info["padded_entries"] >= nnz
-    if window == 0:
-        assert info["padded_entries"] <= 1.35 * nnz       # length-sorted slices keep padding small
-    assert info["n_slices"] == (m["n_reads"] + 255) // 256
-    if window == 256:
-        assert info["far_entries"] > 0                    # cross-family hits fall outside a small window
+    assert info["nnz"] == nnz
+    multi = nnz - info["folded_single_rows"]                # entries of the rows that are stored
+    assert multi - info["exported_entries"] <= info["padded_entries"]      # every stored entry has a forward slot
+    assert info["n_chunks"] == (min(int(chunks), info["n_slices"]) if chunks else min(1024, info["n_slices"]))
+    assert info["n_chunks"] <= info["n_groups"] <= info["n_slices"]
+    assert info["far_entries"] > 0                          # cross-family hits fall outside their row's window ...
+    assert (info["exported_entries"] > 0) == (export == "1")   # ... and leave through the far blocks unless that is switched off
 
 
 def test_layout_roundtrip_edge_cases(lib):
     # empty matrix, empty rows, one row, one very long row, duplicate tids inside a row (SURVEY A2)
-    emsar_amd.layout_selfcheck(5, np.array([0], dtype=np.uint64), np.array([], dtype=np.int32))
-    emsar_amd.layout_selfcheck(5, np.array([0, 0, 0], dtype=np.uint64), np.array([], dtype=np.int32))
-    emsar_amd.layout_selfcheck(5, np.array([0, 1], dtype=np.uint64), np.array([4], dtype=np.int32))
-    emsar_amd.layout_selfcheck(5, np.array([0, 0, 3, 3, 4], dtype=np.uint64), np.array([2, 4, 4, 0], dtype=np.int32))
+    chk = emsar_amd.layout_selfcheck_tiled
+    chk(5, np.array([0], dtype=np.uint64), np.array([], dtype=np.int32))
+    chk(5, np.array([0, 0, 0], dtype=np.uint64), np.array([], dtype=np.int32))
+    chk(5, np.array([0, 1], dtype=np.uint64), np.array([4], dtype=np.int32))
+    chk(5, np.array([0, 0, 3, 3, 4], dtype=np.uint64), np.array([2, 4, 4, 0], dtype=np.int32))
     rng = np.random.default_rng(0)
-    long_row = rng.integers(0, 3000, 700).astype(np.int32)
+    long_row = rng.integers(0, 3000, 700).astype(np.int32)      # 700 scattered tids: far entries beyond one dictionary -> leftover CSR
     rp = np.array([0, 700, 701], dtype=np.uint64)
-    info = emsar_amd.layout_selfcheck(3000, rp, np.append(long_row, 5).astype(np.int32))
-    assert info["n_slices"] == 1 and info["padded_entries"] == 256 * 700
+    info = chk(3000, rp, np.append(long_row, 5).astype(np.int32))
+    assert info["n_slices"] == 0 and info["folded_single_rows"] == 1
+    near_row = (1000 + rng.integers(0, 300, 700)).astype(np.int32)  # 700 tids within one window: one slice of one row
+    info = chk(3000, rp, np.append(near_row, 5).astype(np.int32))
+    assert info["n_slices"] == 1 and info["padded_entries"] == 768 * 700
 
 
 @pytest.mark.parametrize("merge", [False, True])
@@ -121,9 +131,3 @@ def test_tiled_layout_roundtrip_synthetic(lib):
     rp = np.zeros(len(rows) + 1, dtype=np.uint64)
     rp[1:] = np.cumsum([len(r) for r in rows])
     emsar_amd.layout_selfcheck_tiled(8, rp, np.concatenate(rows).astype(np.int32), True)
-
-
-def test_layout_roundtrip_golden(lib, golden):
-    m = golden.model
-    info = emsar_amd.layout_selfcheck(m.n_tx, m.row_ptr, m.col_idx, 256, 2048)
-    assert info["nnz"] == len(m.col_idx)

@@ -6,11 +6,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+template <class T> static bool same_pod(const std::vector<T> &a, const std::vector<T> &b) {
+    return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0);
+}
 static bool same_layout(const emsar::TiledLayout &a, const emsar::TiledLayout &b) {
-    return a.tiles.size() == b.tiles.size() && (a.tiles.empty() || memcmp(a.tiles.data(), b.tiles.data(), a.tiles.size() * sizeof(emsar::Tile)) == 0) &&
+    return same_pod(a.slices, b.slices) && same_pod(a.groups, b.groups) && same_pod(a.chunks, b.chunks) &&
            a.single_row == b.single_row && a.single_tid == b.single_tid && a.slot_row == b.slot_row && a.fwd == b.fwd && a.bwd == b.bwd &&
-           a.coo == b.coo && a.far_tid == b.far_tid && a.left_ptr == b.left_ptr && a.left_col == b.left_col && a.left_row == b.left_row &&
-           a.mem_ptr == b.mem_ptr && a.mem_row == b.mem_row;
+           a.coo == b.coo && a.far_tid == b.far_tid && a.far_blk_tid == b.far_blk_tid && a.far_ptr == b.far_ptr && a.far_pos == b.far_pos &&
+           a.left_ptr == b.left_ptr && a.left_col == b.left_col && a.left_row == b.left_row && a.mem_ptr == b.mem_ptr && a.mem_row == b.mem_row;
 }
 int main(int argc, char **argv) {
     std::mt19937 rng(1);
@@ -27,6 +30,8 @@ int main(int argc, char **argv) {
             for (int j = 0; j < k; j++) ci.push_back(rng() % 10 == 0 ? (int)(rng() % n_tx) : std::min(n_tx - 1, t0 + j % 64));
             rp.push_back(ci.size());
         }
+        if (trial % 3 == 0) setenv("EMSAR_HIP_CHUNKS", trial % 2 ? "3" : "40", 1); else unsetenv("EMSAR_HIP_CHUNKS");
+        if (trial % 5 == 4) setenv("EMSAR_HIP_FAR_EXPORT", "0", 1); else unsetenv("EMSAR_HIP_FAR_EXPORT");
         if (trial % 4 == 1) setenv("EMSAR_HIP_FRAG_ROWS", "3072", 1);          // many independently tiled fragments, several threads
         else if (trial % 4 == 2) setenv("EMSAR_HIP_FRAG_ROWS", "7000", 1);
         else unsetenv("EMSAR_HIP_FRAG_ROWS");
@@ -41,9 +46,6 @@ int main(int argc, char **argv) {
             if (rc || !same_layout(L, L1)) { printf("FAIL trial %d merge %d: layout depends on the thread count\n", trial, merge); return 1; }
             unsetenv("EMSAR_HOST_THREADS");
         }
-        emsar::WindowedLayout W;
-        int rc = emsar::build_windowed(n_rows, n_tx, rp.data(), ci.data(), 256 << (trial % 5), 4096, W);
-        if (rc || emsar::check_windowed(W, rp.data(), ci.data())) { printf("FAIL windowed %d\n", trial); return 1; }
     }
     // set-resident records: sparse family-like matrices (many small sets), weights with zeros, a few huge rows
     for (int trial = 0; trial < n_sets; trial++) {
