@@ -66,9 +66,11 @@ struct emsar_hip_ctx {
     uint32_t *d_fwd = nullptr, *d_bwd = nullptr;
     uint32_t *d_coo = nullptr;
     int32_t *d_far = nullptr;    // explicit dictionary far lists
-    int32_t *d_far_blk = nullptr; double *d_far_w = nullptr; uint32_t *d_far_ptr = nullptr, *d_far_pos = nullptr;   // exported far entries
+    int32_t *d_far_blk = nullptr; double *d_far_w = nullptr; uint32_t *d_far_ptr = nullptr, *d_far_dst = nullptr;   // exported far entries
     int64_t n_far_exported = 0;
+    int64_t n_pairs = 0; int32_t *d_pair_tid = nullptr; uint32_t *d_pair_dst = nullptr; int32_t *d_pair_wgt = nullptr; double *d_pair_val = nullptr;
     int n_wg_slots = 1024;       // workgroups of the pass kernel the device holds at once (4 per CU)
+    unsigned long long *d_stamps = nullptr;   // non-null only inside emsar_hip_debug_chunk_times
     uint64_t *d_left_ptr = nullptr; int32_t *d_left_col = nullptr; int32_t *d_left_wgt = nullptr; double *d_left_val = nullptr;
     int64_t n_left = 0, n_chunks = 0, n_slots = 0;
     double *d_u = nullptr;       // folded single-tid rows: per-transcript weight sum
@@ -148,8 +150,10 @@ void free_structure(emsar_hip_ctx *ctx) {
     ctx->d_row_ptr = nullptr; ctx->d_col = nullptr;
     dfree(ctx->d_wgt); dfree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
     dfree(ctx->d_chunks); dfree(ctx->d_groups); dfree(ctx->d_slices); dfree(ctx->d_fwd); dfree(ctx->d_bwd); dfree(ctx->d_coo); dfree(ctx->d_far);
-    dfree(ctx->d_far_blk); dfree(ctx->d_far_w); dfree(ctx->d_far_ptr); dfree(ctx->d_far_pos);
-    ctx->d_far_blk = nullptr; ctx->d_far_w = nullptr; ctx->d_far_ptr = ctx->d_far_pos = nullptr; ctx->n_far_exported = 0;
+    dfree(ctx->d_far_blk); dfree(ctx->d_far_w); dfree(ctx->d_far_ptr); dfree(ctx->d_far_dst);
+    ctx->d_far_blk = nullptr; ctx->d_far_w = nullptr; ctx->d_far_ptr = ctx->d_far_dst = nullptr; ctx->n_far_exported = 0;
+    dfree(ctx->d_pair_tid); dfree(ctx->d_pair_dst); dfree(ctx->d_pair_wgt); dfree(ctx->d_pair_val);
+    ctx->d_pair_tid = nullptr; ctx->d_pair_dst = nullptr; ctx->d_pair_wgt = nullptr; ctx->d_pair_val = nullptr; ctx->n_pairs = 0;
     dfree(ctx->d_left_ptr); dfree(ctx->d_left_col); dfree(ctx->d_left_wgt); dfree(ctx->d_left_val); dfree(ctx->d_u);
     ctx->d_chunks = nullptr; ctx->d_groups = nullptr; ctx->d_slices = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_coo = nullptr; ctx->d_far = nullptr;
     ctx->d_left_ptr = nullptr; ctx->d_left_col = nullptr; ctx->d_left_wgt = nullptr; ctx->d_left_val = nullptr; ctx->d_u = nullptr;
@@ -163,18 +167,20 @@ void free_structure(emsar_hip_ctx *ctx) {
 
 // the exported far entries of the TILED layout as the update kernels see them (null: none)
 inline FarList far_list(const emsar_hip_ctx *ctx) {
-    if (ctx->layout != EMSAR_LAYOUT_TILED || ctx->n_far_exported == 0) return FarList{nullptr, nullptr, nullptr};
-    return FarList{ctx->d_far_ptr, ctx->d_far_pos, ctx->d_far_w};
+    if (ctx->layout != EMSAR_LAYOUT_TILED || ctx->n_far_exported == 0) return FarList{nullptr, nullptr};
+    return FarList{ctx->d_far_ptr, ctx->d_far_w};
 }
 
 // one pass of the chosen layout.  mode: MODE_EM / MODE_EM_LL / MODE_SCATTER
 int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, double *ll_out, bool rows_only = false /* the folded rows' likelihood terms are added by the caller */) {
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
         const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
-        if (ctx->n_chunks > 0) {
-            dim3 grid((unsigned)ctx->n_chunks), block(kTiledThreads);
-            const TiledArgs A{ctx->d_chunks, ctx->d_groups, ctx->d_slices, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_far_blk, ctx->d_far_w,
-                              ctx->d_wgt, ctx->d_rowval};
+        if (ctx->n_chunks > 0 || ctx->n_pairs > 0) {
+            const int64_t pair_wgs = std::min<int64_t>((ctx->n_pairs + kTiledThreads - 1) / kTiledThreads, ctx->n_wg_slots);
+            dim3 grid((unsigned)std::max<int64_t>(ctx->n_chunks, pair_wgs)), block(kTiledThreads);
+            const TiledArgs A{(int)ctx->n_chunks, ctx->d_chunks, ctx->d_groups, ctx->d_slices, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_far_blk, ctx->d_far_dst,
+                              ctx->d_far_w, ctx->d_wgt, ctx->d_rowval, ctx->n_pairs, ctx->d_pair_tid, ctx->d_pair_dst, ctx->d_pair_wgt,
+                              ctx->d_pair_val, ctx->d_stamps};
 #define LAUNCH_T(WT, MD) hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, A, theta, acc, ll_out)
             if (mode == MODE_SCATTER) LAUNCH_T(false, MODE_SCATTER);
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
@@ -219,7 +225,10 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
 int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_ll, int ll_slot, double abs_floor, int to_delta1 = 0) {
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot].v);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), ctx->update_grid)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
+    // with exported far entries every workgroup iteration is a chain of dependent trips to memory (run bounds -> far_w -> LDS):
+    // one iteration per workgroup, all of them in flight together
+    const int ug = far_list(ctx).ptr ? grid_for(ctx->n_tx, 256) : std::min(grid_for(ctx->n_tx, 256), ctx->update_grid);
+    hipLaunchKernelGGL(k_update, dim3(ug), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
                        ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->zero_cut, ctx->d_scal,
                        ctx->delta_mask, to_delta1, far_list(ctx));
     HIPCHK(hipGetLastError());
@@ -243,12 +252,13 @@ int enqueue_cycles(emsar_hip_ctx *ctx, const emsar_em_params &p, double abs_step
         // the stopping rule is measured on the first (plain) step of the cycle only (delta1_bits)
         const double *u = ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr;
         const dim3 gv((unsigned)std::min(g, ctx->sq_grid)), bv(256);
+        const dim3 gf((unsigned)(far_list(ctx).ptr ? g : std::min(g, ctx->sq_grid)));      // kernels that add the exported far sums
         if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor, 1))) return rc;
         if ((rc = launch_pass(ctx, MODE_EM_LL, th[1], ctx->d_acc, &ctx->d_scal->ll[1].v, true))) return rc;
-        hipLaunchKernelGGL(k_update_p2, gv, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal, far_list(ctx));
+        hipLaunchKernelGGL(k_update_p2, gf, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal, far_list(ctx));
         hipLaunchKernelGGL(k_sq_extrap_ll, gv, bv, 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, u, th[3], ctx->d_scal);
         if ((rc = launch_pass(ctx, MODE_EM_LL, th[3], ctx->d_acc, &ctx->d_scal->ll[2].v, true))) return rc;
-        hipLaunchKernelGGL(k_update_p3, gv, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal, far_list(ctx));
+        hipLaunchKernelGGL(k_update_p3, gf, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal, far_list(ctx));
         HIPCHK(hipGetLastError());
     }
     return EMSAR_HIP_OK;
@@ -277,6 +287,14 @@ int scatter_rows(emsar_hip_ctx *ctx, const double *val_host, double *d_out) {
                 else slot[(size_t)i] = val_host[r];
             }
             for (int64_t i = 0; i < ctx->n_left; i++) left[(size_t)i] = val_host[L.left_row[(size_t)i]];
+            std::vector<double> pairv((size_t)std::max<int64_t>(ctx->n_pairs, 1), 0.0);
+            for (int64_t i = 0; i < ctx->n_pairs; i++) {
+                const int64_t r = L.pair_row[(size_t)i];
+                if (L.merged) { double v = 0; for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) v += val_host[L.mem_row[(size_t)q]]; pairv[(size_t)i] = v; }
+                else pairv[(size_t)i] = val_host[r];
+            }
+            if (!ctx->d_pair_val) HIPCHK(hipMalloc(&ctx->d_pair_val, pairv.size() * sizeof(double)));
+            HIPCHK(hipMemcpyAsync(ctx->d_pair_val, pairv.data(), pairv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
             for (size_t i = 0; i < L.single_row.size(); i++) base[(size_t)L.single_tid[i]] += val_host[L.single_row[i]];
             if (!ctx->d_rowval) HIPCHK(hipMalloc(&ctx->d_rowval, slot.size() * sizeof(double)));
             if (!ctx->d_left_val) HIPCHK(hipMalloc(&ctx->d_left_val, left.size() * sizeof(double)));
@@ -491,7 +509,8 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
             if (brc != 0) { ctx->err = "TILED layout builder: code " + std::to_string(brc); return EMSAR_HIP_ERR_ARG; }
             if (dbg) fprintf(stderr, "upload_structure: layout built after %.0f ms\n", since(tu0));
             ctx->n_chunks = (int64_t)L.chunks.size(); ctx->n_slots = L.n_slots(); ctx->n_left = (int64_t)L.left_row.size();
-            ctx->n_far_exported = (int64_t)L.far_pos.size();
+            ctx->n_far_exported = L.n_exported;
+            ctx->n_pairs = (int64_t)L.pair_row.size();
             auto up = [&](void **dp, const void *src, size_t bytes) -> hipError_t {
                 hipError_t e = hipMalloc(dp, std::max<size_t>(bytes, 16));
                 if (e == hipSuccess && bytes) e = hipMemcpy(*dp, src, bytes, hipMemcpyHostToDevice);
@@ -506,9 +525,11 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
             HIPCHK(up((void **)&ctx->d_far, L.far_tid.data(), L.far_tid.size() * 4));
             HIPCHK(up((void **)&ctx->d_far_blk, L.far_blk_tid.data(), L.far_blk_tid.size() * 4));
             HIPCHK(up((void **)&ctx->d_far_ptr, L.far_ptr.data(), L.far_ptr.size() * 4));
-            HIPCHK(up((void **)&ctx->d_far_pos, L.far_pos.data(), L.far_pos.size() * 4));
-            HIPCHK(hipMalloc(&ctx->d_far_w, std::max<size_t>(L.far_blk_tid.size(), 2) * 8));
-            HIPCHK(hipMemset(ctx->d_far_w, 0, std::max<size_t>(L.far_blk_tid.size(), 2) * 8));
+            HIPCHK(up((void **)&ctx->d_far_dst, L.far_blk_dst.data(), L.far_blk_dst.size() * 4));
+            HIPCHK(up((void **)&ctx->d_pair_tid, L.pair_tid.data(), L.pair_tid.size() * 4));
+            HIPCHK(up((void **)&ctx->d_pair_dst, L.pair_dst.data(), L.pair_dst.size() * 4));
+            HIPCHK(hipMalloc(&ctx->d_far_w, std::max<size_t>((size_t)L.n_exported, 2) * 8));
+            HIPCHK(hipMemset(ctx->d_far_w, 0, std::max<size_t>((size_t)L.n_exported, 2) * 8));
             HIPCHK(up((void **)&ctx->d_left_ptr, L.left_ptr.data(), L.left_ptr.size() * 8));
             HIPCHK(up((void **)&ctx->d_left_col, L.left_col.data(), L.left_col.size() * 4));
             HIPCHK(hipMalloc(&ctx->d_u, T * 8));
@@ -517,13 +538,14 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
             // written by the pass and read back by the update kernel through far_pos)
             ctx->bytes_stored = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 + (int64_t)L.far_tid.size() * 4 +
                                 (int64_t)L.slices.size() * 32 + (int64_t)L.groups.size() * 32 + (int64_t)L.chunks.size() * 8 +
-                                (int64_t)L.far_blk_tid.size() * (4 + 8) + (int64_t)L.far_pos.size() * (4 + 8) + (L.far_pos.empty() ? 0 : (int64_t)L.far_ptr.size() * 4) +
+                                (int64_t)L.far_blk_tid.size() * (4 + 4) + L.n_exported * (8 + 8) + (L.n_exported ? (int64_t)L.far_ptr.size() * 4 : 0) +
+                                (int64_t)L.pair_tid.size() * (4 + 4) +
                                 (int64_t)L.left_col.size() * 4 + (int64_t)L.left_ptr.size() * 8;
             ctx->tl_fwd_slots = L.padded_slots; ctx->tl_n_fslices = (int64_t)L.slices.size();
-            ctx->tl_far_entries = L.far_entries + L.exported_entries;
+            ctx->tl_far_entries = L.far_entries + L.n_exported;
             emsar::u32_vec().swap(L.fwd); emsar::u32_vec().swap(L.bwd); std::vector<uint32_t>().swap(L.coo);
             std::vector<int32_t>().swap(L.left_col); std::vector<int32_t>().swap(L.far_blk_tid);
-            std::vector<uint32_t>().swap(L.far_pos); std::vector<uint32_t>().swap(L.far_ptr);
+            std::vector<uint32_t>().swap(L.far_blk_dst); std::vector<uint32_t>().swap(L.far_ptr);
             const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
 #define SETLDS_T(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             SETLDS_T(false, MODE_EM); SETLDS_T(false, MODE_EM_LL); SETLDS_T(true, MODE_EM); SETLDS_T(true, MODE_EM_LL); SETLDS_T(false, MODE_SCATTER);
@@ -631,6 +653,27 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
                 wl[(size_t)i] = x;
                 if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[r]);
             }
+            std::vector<int32_t> wp((size_t)std::max<int64_t>(ctx->n_pairs, 1), 0);       // the pairs, like the slots
+            for (int64_t i = 0; i < ctx->n_pairs; i++) {
+                const int64_t r = L.pair_row[(size_t)i];
+                int64_t sum = 0;
+                if (L.merged) {
+                    for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) {
+                        const int64_t o = L.mem_row[(size_t)q];
+                        const int32_t x = weight_of(o);
+                        sum += x;
+                        if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[o]);
+                    }
+                } else {
+                    sum = weight_of(r);
+                    if (sum > 0 && row_E) ctx->loglik_const += (double)sum * std::log(row_E[r]);
+                }
+                if (sum > INT32_MAX) return EMSAR_HIP_ERR_ARG;
+                wp[(size_t)i] = (int32_t)sum;
+            }
+            dfree(ctx->d_pair_wgt); ctx->d_pair_wgt = nullptr;
+            HIPCHK(hipMalloc(&ctx->d_pair_wgt, wp.size() * 4));
+            HIPCHK(hipMemcpy(ctx->d_pair_wgt, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMalloc(&ctx->d_wgt, w.size() * 4));
             HIPCHK(hipMemcpy(ctx->d_wgt, w.data(), w.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMalloc(&ctx->d_left_wgt, wl.size() * 4));
@@ -932,6 +975,36 @@ int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *o) {
     return EMSAR_HIP_OK;
 }
 
+// Diagnostic only (not declared in the public header): one stamped pass of the TILED kernel on the current theta (theta is
+// left untouched, acc is cleared again).  out[8 * (4 * chunk + wave) + i]: i = 0 start, 1 end of the wave on the 100 MHz clock,
+// 2 shader cycles spent inside slices, 3 slices processed, 4..7 cycles per phase (loads issued, E-step, weights + next slice's
+// loads, M-step); then, from out[32 * n_chunks], five values per slice: shader cycles, k, m, coo_n, nf | chunk << 8.
+// n_out >= 32 * n_chunks + 5 * n_slices.
+int emsar_hip_debug_chunk_times(emsar_hip_ctx *ctx, unsigned long long *out, int64_t n_out) {
+    if (!ctx || !out || ctx->layout != EMSAR_LAYOUT_TILED || !ctx->have_sample || ctx->n_chunks == 0) return EMSAR_HIP_ERR_STATE;
+    const size_t nw = (size_t)ctx->n_chunks * emsar::kTileWaves * 8, ns = ctx->TL.slices.size(), n = nw + ns;
+    if (n_out < (int64_t)(nw + 5 * ns)) return EMSAR_HIP_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMalloc(&ctx->d_stamps, n * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(ctx->d_stamps, 0, n * sizeof(unsigned long long), ctx->stream);
+    int rc = EMSAR_HIP_OK;
+    std::vector<unsigned long long> tmp(n);
+    if (e == hipSuccess) rc = launch_pass(ctx, MODE_EM, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].v);
+    if (e == hipSuccess && rc == EMSAR_HIP_OK) e = hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream);
+    if (e == hipSuccess && rc == EMSAR_HIP_OK) e = hipMemcpyAsync(tmp.data(), ctx->d_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == EMSAR_HIP_OK) e = hipStreamSynchronize(ctx->stream);
+    dfree(ctx->d_stamps); ctx->d_stamps = nullptr;
+    if (rc) return rc;
+    HIPCHK(e);
+    for (size_t i = 0; i < nw; i++) out[i] = tmp[i];
+    for (size_t i = 0; i < ns; i++) {
+        const emsar::SliceDesc &D = ctx->TL.slices[i];
+        unsigned long long *o = out + nw + 5 * i;
+        o[0] = tmp[nw + i] & ((1ull << 40) - 1); o[1] = D.k; o[2] = D.m; o[3] = D.coo_n; o[4] = D.nf | ((tmp[nw + i] >> 40) << 8);      // nf, and the chunk that ran the slice
+    }
+    return EMSAR_HIP_OK;
+}
+
 int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                                      int merge_rows, emsar_hip_info *info_out) {
     try {
@@ -945,11 +1018,11 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
             info_out->layout = EMSAR_LAYOUT_TILED | (L.merged ? EMSAR_LAYOUT_FLAG_MERGE_ROWS : 0);
             info_out->n_chunks = (int64_t)L.chunks.size();
             info_out->n_slices = (int64_t)L.slices.size();
-            info_out->n_groups = (int64_t)L.groups.size(); info_out->exported_entries = L.exported_entries;
-            info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries + L.exported_entries; info_out->window = emsar::kTileDict;
+            info_out->n_groups = (int64_t)L.groups.size(); info_out->exported_entries = L.n_exported;
+            info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries + L.n_exported; info_out->window = emsar::kTileDict;
             info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 +
                                               (int64_t)L.far_tid.size() * 4 + (int64_t)L.slices.size() * 32 + (int64_t)L.groups.size() * 32 +
-                                              (int64_t)L.far_blk_tid.size() * 12 + (int64_t)L.far_pos.size() * 12 + (int64_t)L.left_col.size() * 4;
+                                              (int64_t)L.far_blk_tid.size() * 8 + L.n_exported * 16 + (int64_t)L.left_col.size() * 4;
             info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
         }
         return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;

@@ -225,6 +225,59 @@ static int alist_add(alist *l, aln x) {
 
 static int cmp_i32(const void *a, const void *b) { int32_t x = *(const int32_t *)a, y = *(const int32_t *)b; return x < y ? -1 : x > y; }
 
+/* ---- read-level rows gathered for emsar_aln_opts.collapse ---------------------------------------------------------- */
+typedef struct { uint64_t *rp; int32_t *ci; int64_t n_rows, cap_rows; uint64_t nnz, cap_nnz; } row_batch;
+
+static void batch_free(row_batch *b) { if (b) { free(b->rp); free(b->ci); free(b); } }
+
+/* hand the gathered rows to the collapse function, look the unique rows up, add their weights (update_rshbucket 'r',
+ * emsar_functions.c:1597-1624: a tid set without an rsh node counts in TotalReadCount but in no ReadCount) */
+static int batch_flush(const emsar_rsh *r, const emsar_aln_opts *o, emsar_counts *c) {
+    row_batch *b = (row_batch *)c->batch;
+    if (!b || b->n_rows == 0) return 0;
+    int rc = 0;
+    int64_t nu = 0;
+    uint64_t *rp_o = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(b->n_rows + 1));
+    int32_t *ci_o = (int32_t *)malloc(sizeof(int32_t) * (size_t)(b->nnz ? b->nnz : 1));
+    int32_t *w_o = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->n_rows);
+    if (!rp_o || !ci_o || !w_o) rc = -1;
+    b->rp[b->n_rows] = b->nnz;
+    if (!rc && o->collapse(o->collapse_user, b->n_rows, r->n_tx, b->rp, b->ci, &nu, rp_o, ci_o, w_o) != 0) rc = -2;
+    for (int64_t u = 0; !rc && u < nu; u++) {
+        const int64_t row = emsar_rsh_row_of(r, ci_o + rp_o[u], (int)(rp_o[u + 1] - rp_o[u]));
+        if (row >= 0) c->R[row] += w_o[u]; else c->reads_no_segment += w_o[u];
+    }
+    free(rp_o); free(ci_o); free(w_o);
+    b->n_rows = 0; b->nnz = 0;
+    return rc;
+}
+
+static int batch_append(const emsar_rsh *r, const emsar_aln_opts *o, emsar_counts *c, const int32_t *sorted, int n) {
+    row_batch *b = (row_batch *)c->batch;
+    if (!b) {
+        b = (row_batch *)calloc(1, sizeof(*b));
+        if (!b) return -1;
+        c->batch = b;
+    }
+    const int64_t limit = o->collapse_batch_rows > 0 ? o->collapse_batch_rows : ((int64_t)4 << 20);
+    if (b->n_rows + 1 >= b->cap_rows) {
+        const int64_t nc = b->cap_rows ? b->cap_rows * 2 : 1 << 16;
+        uint64_t *np = (uint64_t *)realloc(b->rp, sizeof(uint64_t) * (size_t)(nc + 1));
+        if (!np) return -1;
+        b->rp = np; b->cap_rows = nc;
+    }
+    if (b->nnz + (uint64_t)n > b->cap_nnz) {
+        const uint64_t nc = (b->cap_nnz ? b->cap_nnz * 2 : 1 << 18) + (uint64_t)n;
+        int32_t *np = (int32_t *)realloc(b->ci, sizeof(int32_t) * (size_t)nc);
+        if (!np) return -1;
+        b->ci = np; b->cap_nnz = nc;
+    }
+    b->rp[b->n_rows++] = b->nnz;
+    memcpy(b->ci + b->nnz, sorted, sizeof(int32_t) * (size_t)n);
+    b->nnz += (uint64_t)n;
+    return b->n_rows >= limit ? batch_flush(r, o, c) : 0;
+}
+
 /* update_ReadCounts (838-943), positional-bias bookkeeping left out (posmodel is 0 by default and unfinished) */
 static int flush_group(const emsar_rsh *r, const emsar_aln_opts *o, alist *l, emsar_counts *c, int32_t **tmp, int *tmpcap) {
     if (l->n == 0) return 0;
@@ -242,8 +295,12 @@ static int flush_group(const emsar_rsh *r, const emsar_aln_opts *o, alist *l, em
     }
     for (int i = 0; i < l->n; i++) (*tmp)[i] = l->a[i].tid;
     qsort(*tmp, (size_t)l->n, sizeof(int32_t), cmp_i32);             /* the reference insertion-sorts with >= (889) */
-    int64_t row = emsar_rsh_row_of(r, *tmp, l->n);
-    if (row >= 0) c->R[row]++; else c->reads_no_segment++;
+    if (o->collapse && l->n >= 2) {                                   /* counted later, one lookup per distinct id set */
+        if (batch_append(r, o, c, *tmp, l->n) != 0) return -1;
+    } else {
+        int64_t row = emsar_rsh_row_of(r, *tmp, l->n);
+        if (row >= 0) c->R[row]++; else c->reads_no_segment++;
+    }
     c->frag_counts[fl]++;
     c->total_reads++;
     return 0;
@@ -439,6 +496,10 @@ done:
     emsar_lr_close(lr);
     if (!mem_bam) bam_close(bam);
     free(l.a); free(tmp); free(prev); free(line2); free(skip_id); free(end_id);
+    if (rc == EMSAR_HOST_OK && !acc && o->collapse && batch_flush(r, o, c) != 0) {      /* a worker's accumulator is flushed by its owner */
+        rc = EMSAR_HOST_ERR_IO;
+        if (err) snprintf(err, errlen, "the collapse of read-level rows failed");
+    }
     if (rc != EMSAR_HOST_OK) { if (!acc) emsar_counts_free(c); return rc; }
     *out = c;
     return EMSAR_HOST_OK;
@@ -686,6 +747,8 @@ static int count_bam_parallel(const emsar_rsh *r, const char *path, const emsar_
     if (rc == EMSAR_HOST_OK && P.rc != EMSAR_HOST_OK) { rc = P.rc; if (err) snprintf(err, errlen, "%s", P.err); }
     if (rc == EMSAR_HOST_OK && malformed) { rc = EMSAR_HOST_ERR_FORMAT; if (err) snprintf(err, errlen, "malformed BAM record"); }
     if (rc == EMSAR_HOST_ERR_OOM && err) snprintf(err, errlen, "out of memory");
+    for (int t = 0; rc == EMSAR_HOST_OK && o->collapse && t < nt; t++)
+        if (w[t].c && batch_flush(r, o, w[t].c) != 0) { rc = EMSAR_HOST_ERR_IO; if (err) snprintf(err, errlen, "the collapse of read-level rows failed"); }
     if (rc == EMSAR_HOST_OK) {
         for (int t = 0; t < nt && rc == EMSAR_HOST_OK; t++) {
             got |= w[t].got;
@@ -779,5 +842,6 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
 
 void emsar_counts_free(emsar_counts *c) {
     if (!c) return;
+    batch_free((row_batch *)c->batch);
     free(c->R); free(c->frag_counts); free(c);
 }

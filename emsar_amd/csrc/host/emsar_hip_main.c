@@ -38,7 +38,7 @@ typedef struct {
     const char *rsh_path, *outdir, *prefix;
     char **aln; int n_aln;
     emsar_aln_opts ao;
-    int n_round, delta, print_segments, verbose, accel, set_mode;
+    int n_round, delta, print_segments, verbose, accel, set_mode, device_collapse;
     double tol, count_floor, zero_cut, abs_step; int max_iter;
     const char *stats_json;
     const char *rsh_cache;      /* NULL = off, "" = <rsh>.bin, else the path */
@@ -54,7 +54,20 @@ typedef struct {
     double *parse_s;
     double *model_s, *host_s;   /* per sample: model preparation, and all host work of run_sample outside the library calls */
     int *go;              /* start gate: the workers wait until main() knows how many of them exist */
+    emsar_aln_opts ao;    /* the job's alignment options, plus this worker's collapse device when --device-collapse */
+    struct { emsar_hip_ctx *ctx; pthread_mutex_t mu; } cdev;
 } worker_arg;
+
+/* emsar_aln_opts.collapse on the GPU (--device-collapse): the parse threads of a worker hand their read-level rows to a context
+ * of their own on the worker's device (the solve context is busy with the sample before); one call at a time */
+static int cli_collapse(void *user, int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
+                        int64_t *n_unique, uint64_t *row_ptr_out, int32_t *col_idx_out, int32_t *weight_out) {
+    worker_arg *w = (worker_arg *)user;
+    pthread_mutex_lock(&w->cdev.mu);
+    const int rc = emsar_hip_collapse_rows(w->cdev.ctx, n_rows, n_tx, row_ptr, col_idx, NULL, n_unique, row_ptr_out, col_idx_out, weight_out, NULL, NULL);
+    pthread_mutex_unlock(&w->cdev.mu);
+    return rc;
+}
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
@@ -64,7 +77,7 @@ typedef struct { worker_arg *w; int i; emsar_counts *cnt; int rc; char err[512];
 static void *parse_main(void *a) {
     parse_job *j = (parse_job *)a;
     double t0 = now_s();
-    j->rc = emsar_count_alignments(j->w->rsh, j->w->cfg->aln[j->i], &j->w->cfg->ao, &j->cnt, j->err, sizeof j->err);
+    j->rc = emsar_count_alignments(j->w->rsh, j->w->cfg->aln[j->i], &j->w->ao, &j->cnt, j->err, sizeof j->err);
     j->secs = now_s() - t0;
     return NULL;
 }
@@ -191,8 +204,16 @@ static void *worker_main(void *a) {
     pthread_mutex_lock(w->mu);
     while (!*w->go) pthread_cond_wait(w->cv, w->mu);                 /* n_workers is final from here on */
     pthread_mutex_unlock(w->mu);
+    w->ao = w->cfg->ao;
+    int crc = 0;
+    if (w->cfg->device_collapse) {                                    /* before the first parse thread starts: it needs the device */
+        pthread_mutex_init(&w->cdev.mu, NULL);
+        crc = emsar_hip_create(&w->cdev.ctx, w->device);
+        if (crc == 0) { w->ao.collapse = cli_collapse; w->ao.collapse_user = w; }
+        else fprintf(stderr, "GPU %d: %s (--device-collapse)\n", w->device, emsar_hip_strerror(crc));
+    }
     if (w->worker < w->cfg->n_aln) parse_start(&slot[c], w, w->worker);
-    int rc = emsar_hip_create(&ctx, w->device);
+    int rc = crc ? crc : emsar_hip_create(&ctx, w->device);
     if (rc == 0) rc = emsar_hip_upload_structure(ctx, w->rsh->n_rows, w->rsh->n_tx, w->rsh->row_ptr, w->rsh->col_idx, EMSAR_LAYOUT_AUTO);
     if (rc == 0) rc = emsar_hip_upload_euma(ctx, w->rsh->euma, w->rsh->nfl);     /* once per rsh: compute_adjEUMA runs on the device */
     if (rc) fprintf(stderr, "GPU %d: %s\n", w->device, emsar_hip_strerror(rc));
@@ -214,6 +235,7 @@ static void *worker_main(void *a) {
         c ^= 1;
     }
     emsar_hip_destroy(ctx);
+    if (w->cfg->device_collapse) { emsar_hip_destroy(w->cdev.ctx); pthread_mutex_destroy(&w->cdev.mu); }
     return NULL;
 }
 
@@ -236,6 +258,8 @@ static void usage(const char *a0) {
             "      --abs-step <x>        components that move by less than x FPKM per pass count as converged (default 1e-13; 0 = off)\n"
             "      --rsh-cache[=file]    read the parsed index from a binary cache (default <rshfile>.bin), write it after a text parse\n"
             "      --streaming-only      do not split the problem into connected sets (every pass streams the whole matrix)\n"
+            "      --device-collapse     reads with two or more transcripts are merged into weighted segments on the GPU\n"
+            "                            (emsar_hip_collapse_rows) instead of one index lookup per read on the host; same counts\n"
             "      --gpus <n> / --devices <a,b,..> (-M: one worker per entry, ids may repeat) / --device <d> / --plain /\n"
             "      --stats-json <file> / -q / -v\n", a0);
 }
@@ -254,7 +278,7 @@ int main(int argc, char **argv) {
         {"print_segments", no_argument, 0, 'g'}, {"multisample", no_argument, 0, 'M'}, {"SAM", no_argument, 0, 'S'}, {"BAM", no_argument, 0, 'B'},
         {"verbose", no_argument, 0, 'v'}, {"no_verbose", no_argument, 0, 'q'}, {"gpus", required_argument, 0, 1000},
         {"device", required_argument, 0, 1001}, {"plain", no_argument, 0, 1002}, {"stats-json", required_argument, 0, 1003},
-        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005}, {"rsh-cache", optional_argument, 0, 1006}, {"zero-cut", required_argument, 0, 1007}, {"abs-step", required_argument, 0, 1008}, {"devices", required_argument, 0, 1009},
+        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005}, {"rsh-cache", optional_argument, 0, 1006}, {"zero-cut", required_argument, 0, 1007}, {"abs-step", required_argument, 0, 1008}, {"devices", required_argument, 0, 1009}, {"device-collapse", no_argument, 0, 1010},
         {"maxfraglen", required_argument, 0, 'F'}, {"minfraglen", required_argument, 0, 'f'}, {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "vqPs:p:F:f:n:e:d:gMSBk:i:I:", lo, NULL)) != -1) {
@@ -284,6 +308,7 @@ int main(int argc, char **argv) {
             case 1006: cfg.rsh_cache = optarg ? optarg : ""; break;
             case 1007: cfg.zero_cut = atof(optarg); break;
             case 1008: cfg.abs_step = atof(optarg); break;
+            case 1010: cfg.device_collapse = 1; break;
             case 1009: {
                 const char *q = optarg;
                 while (*q && n_dev_map < 64) {
@@ -391,7 +416,7 @@ int main(int argc, char **argv) {
     int go = 0, n_started = 1;
     for (int g = 0; g < n_workers; g++)
         wa[g] = (worker_arg){&cfg, rsh, multisample ? dev_map[g] : device, n_workers, g, &mu, &cv, &next_model, &eumacut, status, stats, parse_s,
-                             model_s, host_s, &go};
+                             model_s, host_s, &go, cfg.ao, {NULL, PTHREAD_MUTEX_INITIALIZER}};
     for (int g = 1; g < n_workers; g++) {
         if (pthread_create(&th[g], NULL, worker_main, &wa[g]) != 0) { fprintf(stderr, "warning: worker %d could not be started, using %d\n", g, g); break; }
         n_started++;

@@ -68,11 +68,24 @@ struct emsar_pbgzf *emsar_pbgzf_open(const char *path);
 long emsar_pbgzf_read(struct emsar_pbgzf *p, void *dst, size_t n);
 void emsar_pbgzf_close(struct emsar_pbgzf *p);
 
+/* Optional collapse of read-level rows OUTSIDE this library (emsar_hip_collapse_rows has exactly this signature behind a
+ * context): rows with the same multiset of ids become one row with the number of members as its weight; ids sorted in the
+ * output; the caller provides the three output arrays at worst-case size.  0 = ok. */
+typedef int (*emsar_collapse_fn)(void *user, int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
+                                 int64_t *n_unique_out, uint64_t *row_ptr_out, int32_t *col_idx_out, int32_t *weight_out);
+
 typedef struct {
     int pe;              /* -P */
     char strand;         /* library_strand_type: 0, '+', '-'  (set_library_strand_type, emsar_functions.c:16-22) */
     int max_repeat;      /* -k, default 100 */
     int format;          /* 0 default-bowtie text, 1 SAM text, 2 BAM */
+    /* update_ReadCounts (emsar_functions.c:838-943) in two halves: the filters stay here, read by read; with `collapse` set, the
+     * kept reads with two or more transcripts are not looked up one by one but gathered as read-level rows (sorted ids) and handed
+     * to `collapse` in batches of `collapse_batch_rows`; only the UNIQUE rows that come back are looked up in the rsh, their
+     * weights added to ReadCount.  Same counts as the per-read path, by construction.  NULL = per-read lookup. */
+    emsar_collapse_fn collapse;
+    void *collapse_user;
+    int64_t collapse_batch_rows;     /* <= 0: 4M rows */
 } emsar_aln_opts;
 
 typedef struct {
@@ -83,6 +96,7 @@ typedef struct {
     int64_t total_reads;     /* TotalReadCount */
     int64_t reads_seen, reads_over_k, reads_bad_fraglen, reads_discrepant, reads_no_segment;   /* bookkeeping only */
     int32_t readlength;      /* PE: learnt from the data when the header says -1 */
+    void *batch;             /* private: read-level rows waiting for emsar_aln_opts.collapse */
 } emsar_counts;
 
 int  emsar_set_strand(const char *strand_type, int pe, char *out);   /* "ns","ssf","ssr","ssfr","ssrf" */

@@ -4,6 +4,13 @@
 
 namespace {
 
+// LDS reads in flight per gather batch (experiment knobs; 12 = a whole int4 of ids, 6 = half: 18 fewer VGPRs)
+#ifndef EMSAR_E_BATCH
+#define EMSAR_E_BATCH 6
+#endif
+#ifndef EMSAR_M_BATCH
+#define EMSAR_M_BATCH 12
+#endif
 constexpr int kTiledThreads = 64 * emsar::kTileWaves;     // 4 wavefronts, each working on one slice at a time
 constexpr int kRPL = emsar::kRowsPerLane;                 // 12 rows per lane = twelve 10-bit ids per int4
 constexpr int kTiledWr = emsar::kTileSliceRows + 8;       // w_r of one slice (768) + the zero padding row
@@ -176,8 +183,8 @@ __device__ __forceinline__ double sum_log_rows(const double (&S)[N]) {
 //       E          the wave owns the slice's 768 rows (lane l holds rows 64*i + l, i < 12): S_r = sum th_w[id] (LDS reads only,
 //                  10-bit ids, padding reads the zero slot: no branches); the rows of the last one or two fields may carry an
 //                  EXPORTED far entry: its theta is gathered from global memory straight into that field's sum
-//                  w_r = R_r / S_r -> the wave's own 6 KiB of LDS; the far fields' w_r also go to far_w (consumed by the update
-//                  kernels through far_ptr / far_pos: no dictionary slot, no atomic)
+//                  w_r = R_r / S_r -> the wave's own 6 KiB of LDS; the far fields' w_r also go to far_w, each to its entry's place in
+//                  transcript order (the update kernels add the contiguous run of a transcript: no dictionary slot, no atomic)
 //       M          the SAME wave walks the transposed index of its rows: a lane's segments (column id + 11 row ids) are
 //                  consecutive in column order; it gathers w_r from LDS into a register sum and adds it to acc_w when the
 //                  column changes; tiny columns via a COO list.  No barrier between E and M, none between slices.
@@ -186,14 +193,43 @@ __device__ __forceinline__ double sum_log_rows(const double (&S)[N]) {
 // loaded and flushed once per group (tens of slices), not once per 4 slices.
 // ------------------------------------------------------------------------------------------------
 struct TiledArgs {
+    int n_chunks;                   // workgroups beyond this only take pairs (a matrix of single-transcript rows and pairs has no chunk)
     const emsar::ChunkDesc *chunks; const emsar::GroupDesc *groups; const emsar::SliceDesc *slices;
     const uint32_t *fwd, *bwd, *coo;
     const int32_t *far_dict;        // explicit dictionary far lists
-    const int32_t *far_blk_tid;     // exported far entries: [block][64]
-    double *far_w;                  // their rows' weights, same indexing
+    const int32_t *far_blk_tid;     // exported far entries: [block][64] far tid (-1 = none)
+    const uint32_t *far_blk_dst;    //                       [block][64] place of the row's weight in far_w (0xFFFFFFFF = none)
+    double *far_w;                  // weights of the rows with an exported entry, in transcript order
     const int32_t *wgt;             // per row slot (WEIGHTED)
     const double *rowval;           // per row slot (MODE_SCATTER)
+    // pairs: rows of two transcripts far from each other (layout_tiled.hpp): tids [2 n], places in far_w [2 n], weights / scatter values [n]
+    int64_t n_pairs; const int32_t *pair_tid; const uint32_t *pair_dst; const int32_t *pair_wgt; const double *pair_val;
+    unsigned long long *stamps;     // diagnostic runs only (emsar_hip_debug_chunk_times), else null: per wave {start, end (100 MHz
+                                    // clock), cycles spent inside slices, slices processed}, then one cycle count per slice;
+                                    // read by nobody else
 };
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long stamp_real() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+// the first loads of a slice: its far tids (they come back first) and its first 8 forward columns
+template <int MODE>
+__device__ __forceinline__ void slice_head(const TiledArgs &P, const emsar::SliceDesc &D, unsigned lane, int4 (&A)[8], int &ft0, int &ft1) {
+    if (MODE == MODE_SCATTER) return;
+    const int k = __builtin_amdgcn_readfirstlane((int)D.k), nf = __builtin_amdgcn_readfirstlane((int)D.nf);
+    const unsigned far_blk = __builtin_amdgcn_readfirstlane(D.far_blk);
+    if (nf > 0) ft0 = __builtin_nontemporal_load(&P.far_blk_tid[(size_t)far_blk * 64 + lane]);
+    if (nf > 1) ft1 = __builtin_nontemporal_load(&P.far_blk_tid[(size_t)(far_blk + 1) * 64 + lane]);
+    const int4 *e = reinterpret_cast<const int4 *>(P.fwd) + (size_t)__builtin_amdgcn_readfirstlane(D.fwd_kib) * 64;
+    load8_clamped(A, e, lane, k < 8 ? k : 8);
+}
 
 template <bool WEIGHTED, int MODE>
 __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs P, const double *__restrict__ theta, double *__restrict__ acc,
@@ -210,8 +246,15 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
     const unsigned th_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(th_w));
     const unsigned ws_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(w_s));
     if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;      // padding row of this wave's slices
-    const emsar::ChunkDesc C = P.chunks[blockIdx.x];
+    const emsar::ChunkDesc C = (int)blockIdx.x < P.n_chunks ? P.chunks[blockIdx.x] : emsar::ChunkDesc{0u, 0u};
     double ll = 0.0;
+    const bool stamped = P.stamps != nullptr;                     // uniform; the timed runs never take these branches
+    unsigned long long t_begin = 0, t_slices = 0, n_done = 0, t_ph[4] = {0, 0, 0, 0};   // phases: issue, E, w + next-slice issue, M
+    if (stamped) t_begin = stamp_real();
+    // (Tried and dropped: slices handed out by a counter in GLOBAL memory so that workgroups that finish early can help the
+    // others -- all 1024 workgroups are resident from the first cycle to the last and the hardware issues the oldest waves
+    // first, so the first workgroup of a CU finishes an equal share 20 % before the fourth.  A returning global atomic per slice
+    // sits in the wave's in-order memory queue in front of every later load: 187 -> 292 us per pass.)
     for (unsigned g = C.group_begin; g < C.group_end; g++) {
         const emsar::GroupDesc G = P.groups[g];
         const int near_n = (int)G.near_n, nd = near_n + (int)G.far_n;
@@ -226,29 +269,46 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
         }
         if (threadIdx.x == 0) next_slice = G.slice_begin + emsar::kTileWaves;
         __syncthreads();
-        unsigned s = G.slice_begin + (unsigned)wave;                       // wave-uniform
+        // The wave's slices, software-pipelined: while slice s is in its M-step (LDS only), the forward columns and far tids of
+        // the wave's NEXT slice are already on their way into the registers the E-step has just released -- a wave that asked for
+        // its loads only when it needed them spent a third of its life waiting for HBM with the LDS pipe idle.
+        unsigned s = G.slice_begin + (unsigned)wave;                       // wave-uniform; the first four slices are dealt, the rest
+        emsar::SliceDesc D;                                                // come from the group's counter in LDS
+        int4 A[8];
+        int ft0 = -1, ft1 = -1;
+        if (s < G.slice_end) { D = P.slices[s]; slice_head<MODE>(P, D, ulane, A, ft0, ft1); }
         while (s < G.slice_end) {
-            const emsar::SliceDesc D = P.slices[s];
+            const unsigned long long ts0 = stamped ? stamp_now() : 0ull;
+#ifdef EMSAR_TILED_PRIO
+            // the hardware issues by priority, then age: a wave's priority changes from slice to slice (a hash of the slice number),
+            // so that no workgroup of a CU is served first for the whole kernel
+            switch ((s * 2654435761u >> 13) & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+#endif
             const int k = __builtin_amdgcn_readfirstlane((int)D.k), m = __builtin_amdgcn_readfirstlane((int)D.m);
             const int nf = __builtin_amdgcn_readfirstlane((int)D.nf);
             const unsigned coo_n = __builtin_amdgcn_readfirstlane((unsigned)D.coo_n), coo_base = __builtin_amdgcn_readfirstlane(D.coo_off);
             const unsigned far_blk = __builtin_amdgcn_readfirstlane(D.far_blk);
             const int4 *e = reinterpret_cast<const int4 *>(P.fwd) + (size_t)__builtin_amdgcn_readfirstlane(D.fwd_kib) * 64;   // wave-uniform
             const int4 *b = reinterpret_cast<const int4 *>(P.bwd) + (size_t)__builtin_amdgcn_readfirstlane(D.bwd_kib) * 64;
-            // ---- every global load the slice needs first, in the order of use ----
-            int ft0 = -1, ft1 = -1;
-            if (MODE != MODE_SCATTER) {
-                if (nf > 0) ft0 = __builtin_nontemporal_load(&P.far_blk_tid[(size_t)far_blk * 64 + lane]);
-                if (nf > 1) ft1 = __builtin_nontemporal_load(&P.far_blk_tid[(size_t)(far_blk + 1) * 64 + lane]);
-            }
-            int4 A[8], B[8];
-            if (MODE != MODE_SCATTER) load8_clamped(A, e, ulane, k < 8 ? k : 8);
+            // ---- the rest of this slice's loads: 8 backward segments, theta of the far entries, where their weights go ----
+            int4 B[8];
             if (m > 0) load8_clamped(B, b, ulane, m < 8 ? m : 8);
             double fv0 = 0.0, fv1 = 0.0;                                   // theta of the exported far entries of fields 11 / 10
             if (MODE != MODE_SCATTER) {
                 if (ft0 >= 0) fv0 = theta[ft0];
                 if (ft1 >= 0) fv1 = theta[ft1];
             }
+            // requested now (in the registers the far tids have just left), needed at the end of the E-step -- asked for only
+            // then, each far block cost the wave a full trip to HBM
+            unsigned dst0 = 0xFFFFFFFFu, dst1 = 0xFFFFFFFFu;
+            if (nf > 0) dst0 = __builtin_nontemporal_load(&P.far_blk_dst[(size_t)far_blk * 64 + lane]);
+            if (nf > 1) dst1 = __builtin_nontemporal_load(&P.far_blk_dst[(size_t)(far_blk + 1) * 64 + lane]);
+            const unsigned long long tp1 = stamped ? stamp_now() : 0ull;
             // ---- E: row sums of the slice's 768 rows ----
             // row i of lane l is slot 64*i + l of the slice: the lanes of one gather hold consecutive sorted rows
             const size_t slot0 = (size_t)s * emsar::kTileSliceRows + lane;
@@ -263,7 +323,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
                 for (int j0 = 0; j0 < k; j0 += 8) {
                     const int n0 = k - j0 < 8 ? k - j0 : 8;
                     if (j0) load8_clamped(A, e + (size_t)j0 * 64, ulane, n0);
-                    fwd_sum_regs(A, n0, th_base, S);
+                    fwd_sum_regs<EMSAR_E_BATCH>(A, n0, th_base, S);
                 }
                 S[kRPL - 1] += fv0; S[kRPL - 2] += fv1;
                 double r[kRPL];
@@ -281,22 +341,30 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
                 }
                 if (MODE == MODE_EM_LL && !WEIGHTED) ll += sum_log_rows(S);
             }
+            const unsigned long long tp2 = stamped ? stamp_now() : 0ull;
 #pragma unroll
             for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = w[i];
-            if (nf > 0) P.far_w[(size_t)far_blk * 64 + lane] = w[kRPL - 1];
-            if (nf > 1) P.far_w[(size_t)(far_blk + 1) * 64 + lane] = w[kRPL - 2];
             // the M-step below reads rows written by OTHER lanes of this same wave: DS operations of one wave execute in
             // order, so only the compiler has to be kept from moving the reads up
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- the wave's next slice: its number from the group's counter, its first loads into the forward registers (the row weights are
+            // in LDS by now: the registers of both are free) ----
+            unsigned nx = 0;
+            if (lane == 0) nx = __hip_atomic_fetch_add(&next_slice, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned sn = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
+            emsar::SliceDesc Dn = D;
+            int ftn0 = -1, ftn1 = -1;
+            if (sn < G.slice_end) { Dn = P.slices[sn]; slice_head<MODE>(P, Dn, ulane, A, ftn0, ftn1); }
+            const unsigned long long tp3 = stamped ? stamp_now() : 0ull;
             // ---- M: column sums over the same 768 rows, through the slice's transposed index ----
             unsigned cur = 0xFFFFFFFFu;
             double part = 0.0;
             for (int j0 = 0; j0 < m; j0 += 8) {
                 const int n0 = m - j0 < 8 ? m - j0 : 8;
                 if (j0) load8_clamped(B, b + (size_t)j0 * 64, ulane, n0);
-                bwd_sum_regs(B, n0, ws_base, acc_w, cur, part);
+                bwd_sum_regs<EMSAR_M_BATCH>(B, n0, ws_base, acc_w, cur, part);
             }
             if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
             for (unsigned q = lane; q < coo_n; q += 64) {
@@ -304,13 +372,24 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
                 const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
                 if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + ((p >> 16) << 3)), v);
             }
+            // The far rows' weights leave for far_w only now, read back from LDS.  A wave's loads and stores complete in issue order
+            // (one vmcnt counter): scattered 8-byte stores issued before the M-step would stand in front of every load the M-step
+            // waits for (its reloads of backward segments); here the next loads waited for are the next slice's forward columns,
+            // requested before these stores.
+            if (dst0 != 0xFFFFFFFFu) P.far_w[dst0] = w_s[64 * (kRPL - 1) + lane];
+            if (dst1 != 0xFFFFFFFFu) P.far_w[dst1] = w_s[64 * (kRPL - 2) + lane];
             // the next slice's E-step overwrites w_s: again only the compiler needs telling
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            unsigned nx = 0;
-            if (lane == 0) nx = __hip_atomic_fetch_add(&next_slice, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            s = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
+            if (stamped) {
+                const unsigned long long te = stamp_now();
+                const unsigned long long dt = te - ts0;
+                t_slices += dt; n_done++;
+                t_ph[0] += tp1 - ts0; t_ph[1] += tp2 - tp1; t_ph[2] += tp3 - tp2; t_ph[3] += te - tp3;
+                if (lane == 0) P.stamps[(size_t)gridDim.x * emsar::kTileWaves * 8 + s] = dt | ((unsigned long long)blockIdx.x << 40);
+            }
+            s = sn; D = Dn; ft0 = ftn0; ft1 = ftn1;
         }
         __syncthreads();
         // ---- flush the dictionary ----
@@ -323,6 +402,25 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
         }
         // a thread rewrites only the dictionary slots it has just flushed (same d -> thread mapping), next_slice is rewritten
         // by thread 0 and read by nobody before the next barrier: no barrier needed here
+    }
+    // ---- the pairs: every workgroup takes its share after its chunk (two theta gathers, one division, two stores per row) ----
+    for (int64_t i = (int64_t)blockIdx.x * kTiledThreads + threadIdx.x; i < P.n_pairs; i += (int64_t)gridDim.x * kTiledThreads) {
+        double w;
+        if (MODE == MODE_SCATTER) w = P.pair_val[i];
+        else {
+            const double S = theta[P.pair_tid[2 * i]] + theta[P.pair_tid[2 * i + 1]];
+            const double r = WEIGHTED ? (double)P.pair_wgt[i] : 1.0;
+            const bool live = (S > 0.0) && (r > 0.0);
+            w = live ? r / S : 0.0;
+            if (MODE == MODE_EM_LL && live) ll += r * log(S);
+        }
+        P.far_w[P.pair_dst[2 * i]] = w;
+        P.far_w[P.pair_dst[2 * i + 1]] = w;
+    }
+    if (stamped && lane == 0) {
+        unsigned long long *o = P.stamps + ((size_t)blockIdx.x * emsar::kTileWaves + wave) * 8;
+        o[0] = t_begin; o[1] = stamp_real(); o[2] = t_slices; o[3] = n_done;
+        o[4] = t_ph[0]; o[5] = t_ph[1]; o[6] = t_ph[2]; o[7] = t_ph[3];
     }
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);

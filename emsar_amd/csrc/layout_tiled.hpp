@@ -20,9 +20,13 @@
 //     atomics.  The first far entry of a row is therefore EXPORTED: the row is placed in one of the last fields of its slice
 //     (field 11, then 10: at most 128 such rows per slice), the far tid goes to a per-slice FAR BLOCK of 64 tids that the
 //     lanes of the wave gather straight from theta into the register that holds that field's row sum, and the row's weight
-//     w_r is written to far_w[block][lane]; the update kernels add sum_e far_w[far_pos[e]] over the exported entries e of
-//     transcript t (far_ptr / far_pos, a CSR by transcript) to acc_t -- no dictionary slot, no atomic, fixed summation order.
+//     w_r is stored to far_w[far_dst[block][lane]]: far_w lists the exported entries in TRANSCRIPT order, so the update kernels
+//     add the contiguous run far_w[far_ptr[t] .. far_ptr[t+1]) to acc_t -- no dictionary slot, no atomic, no gather, fixed
+//     summation order.
 //     Further far entries of the same row (rare) keep explicit dictionary slots (the group's far list);
+//     A row of exactly TWO transcripts that are far from each other (a read with one hit here and one in another family) is a
+//     PAIR: it never enters a slice; the pass kernel computes w = R / (theta_a + theta_b) from two gathers and stores it to far_w
+//     twice, once for each transcript (slices full of such rows would need a far entry for every row);
 //   * consecutive slices whose near entries fit one window of <= 959 transcripts form a GROUP: one dictionary, loaded
 //     once, flushed once; the waves of the workgroup take the group's slices one after another (no barrier in between);
 //   * the slices are cut into CHUNKS of equal work, one workgroup each (as many chunks as the device holds workgroups, so
@@ -60,6 +64,7 @@ constexpr int kSliceDwords = kTileSliceRows / 3;    // dwords per forward column
 constexpr int kFarReach = 200;         // |tid - anchor| beyond this: a far entry (block 512 + 2 x 200 < 959)
 constexpr int kMaxFarBlocks = 2;       // far blocks (64 exported rows each) per slice
 constexpr int64_t kSliceEntries = 65535;   // entries of one slice (16-bit COO count)
+constexpr uint32_t kFarHot = 4096;     // a transcript that is the far hit of more rows than this keeps dictionary slots (see export_index)
 
 // field i (0..11) of a packed int4: dword i/3, bits 10*(i%3) .. +10
 inline void pack10(uint32_t *q, int i, uint32_t id) { q[i / 3] |= (id & 0x3FFu) << (10 * (i % 3)); }
@@ -121,8 +126,13 @@ struct TiledLayout {
     std::vector<int32_t> far_tid;       // explicit dictionary far lists of the groups
     // exported far entries
     std::vector<int32_t> far_blk_tid;   // [n_far_blocks][64]: far tid of the row in (block, lane), -1 = none
-    std::vector<uint32_t> far_ptr;      // [n_tx + 1]: exported entries by transcript ...
-    std::vector<uint32_t> far_pos;      // ... -> 64 * block + lane (index into far_w)
+    std::vector<uint32_t> far_blk_dst;  // [n_far_blocks][64]: where that row's weight goes in far_w (0xFFFFFFFF = none)
+    std::vector<uint32_t> far_ptr;      // [n_tx + 1]: exported entries by transcript: far_w[far_ptr[t] .. far_ptr[t+1])
+    int64_t n_exported = 0;             // = far_ptr[n_tx]
+    // pairs: rows of two transcripts far from each other, both entries exported
+    std::vector<int64_t> pair_row;      // original row, or merged-row id when `merged`
+    std::vector<int32_t> pair_tid;      // [2 n_pairs]
+    std::vector<uint32_t> pair_dst;     // [2 n_pairs] places in far_w
     // leftover rows (too long for a slice): plain CSR + original row ids
     std::vector<uint64_t> left_ptr;
     std::vector<int32_t> left_col;
@@ -162,7 +172,8 @@ inline void run_on_threads(int nt, F fn) {
 //             COO       dword reads [coo_off, coo_off + coo_n)
 //             far blocks [far_blk, far_blk + nf), nf <= kMaxFarBlocks, every tid in it -1 or inside [0, n_tx)
 //             row slots [768 i, 768 i + 768)   (weights, scatter values, slot_row)
-//   far_pos   every entry < 64 * n_far_blocks
+//   pairs     two tids inside [0, n_tx) and two places < n_exported each
+//   far_blk_dst  every entry < n_exported (the length of far_w) exactly where far_blk_tid holds a tid
 // 0 = fine, else a negative code naming the first violated rule.
 inline int check_tiled_extents(const TiledLayout &L) {
     const uint64_t n_fwd = (uint64_t)L.fwd.size() / 4, n_bwd = (uint64_t)L.bwd.size() / 4;     // int4 units
@@ -185,11 +196,19 @@ inline int check_tiled_extents(const TiledLayout &L) {
     }
     for (int32_t t : L.far_blk_tid) if (t < -1 || t >= L.n_tx) return -33;
     if ((uint64_t)L.slices.size() * kTileSliceRows != (uint64_t)L.slot_row.size()) return -30;
-    if (L.far_ptr.size() != (size_t)L.n_tx + 1 || L.far_ptr.front() != 0 || L.far_ptr.back() != L.far_pos.size()) return -34;
+    if (L.far_ptr.size() != (size_t)L.n_tx + 1 || L.far_ptr.front() != 0 || (int64_t)L.far_ptr.back() != L.n_exported) return -34;
     for (size_t t = 0; t + 1 < L.far_ptr.size(); t++) if (L.far_ptr[t] > L.far_ptr[t + 1]) return -34;
-    for (uint32_t p : L.far_pos) if ((uint64_t)p >= 64 * n_blk) return -34;
+    if (L.far_blk_dst.size() != L.far_blk_tid.size()) return -34;
+    for (size_t i = 0; i < L.far_blk_dst.size(); i++) {
+        const uint32_t d = L.far_blk_dst[i];
+        if ((d == 0xFFFFFFFFu) != (L.far_blk_tid[i] < 0)) return -34;
+        if (d != 0xFFFFFFFFu && (int64_t)d >= L.n_exported) return -34;
+    }
     if (L.left_ptr.size() != L.left_row.size() + 1 || (L.left_ptr.empty() ? 0 : L.left_ptr.back()) != (uint64_t)L.left_col.size()) return -31;
     if (L.single_row.size() != L.single_tid.size()) return -32;
+    if (L.pair_tid.size() != 2 * L.pair_row.size() || L.pair_dst.size() != L.pair_tid.size()) return -35;
+    for (size_t i = 0; i < L.pair_tid.size(); i++)
+        if (L.pair_tid[i] < 0 || L.pair_tid[i] >= L.n_tx || (int64_t)L.pair_dst[i] >= L.n_exported) return -35;
     return 0;
 }
 
@@ -290,6 +309,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     if (const char *e = getenv("EMSAR_HIP_FAR_REACH")) { int v = atoi(e); if (v >= 1 && v <= kFarReach) far_reach = v; }
     bool far_export = true;               // EMSAR_HIP_FAR_EXPORT=0: no entry is exported, every far entry keeps a dictionary slot
     if (const char *e = getenv("EMSAR_HIP_FAR_EXPORT")) far_export = atoi(e) != 0;
+    uint32_t far_hot = kFarHot;
+    if (const char *e = getenv("EMSAR_HIP_FAR_HOT")) { long v = atol(e); if (v >= 1) far_hot = (uint32_t)std::min<long>(v, 1 << 30); }
     std::vector<int32_t> mintid((size_t)n_rows, -1);      // the anchor tid of every tiled row (see below)
     bool anchor_median = true;
     if (const char *e = getenv("EMSAR_HIP_TILE_ANCHOR")) anchor_median = atoi(e) != 0;
@@ -317,7 +338,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     std::vector<uint32_t> act;                             // the tiled rows, ascending
     {
         // every thread classifies a contiguous range of rows into lists of its own; the lists are joined in range order
-        struct Part { std::vector<uint32_t> single_row, left_row, act; std::vector<int32_t> single_tid, left_col; std::vector<uint64_t> left_len; };
+        struct Part { std::vector<uint32_t> single_row, left_row, act; std::vector<int32_t> single_tid, left_col, pair_tid; std::vector<uint64_t> left_len; std::vector<int64_t> pair_row; };
         std::vector<Part> part((size_t)std::max(1, n_host));
         const int np = par_ranges(n_rows, [&](int t, int64_t lo, int64_t hi) {
             Part &P = part[(size_t)t];
@@ -326,6 +347,10 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 if (len == 0) continue;
                 const uint32_t r_orig = merge_rows ? orig_of_merged[(size_t)r] : (uint32_t)r;   // singles / long rows are never merged
                 if (len == 1) { P.single_row.push_back(r_orig); P.single_tid.push_back(col_idx[b]); continue; }
+                if (len == 2 && far_export) {
+                    const int32_t ta = col_idx[b], tb = col_idx[b + 1];
+                    if ((ta > tb ? ta - tb : tb - ta) > far_reach) { P.pair_row.push_back(r); P.pair_tid.push_back(ta); P.pair_tid.push_back(tb); continue; }
+                }
                 bool too_wide = false;                        // near span + far entries beyond one dictionary (only possible for len > 550)
                 if (len > (uint64_t)(kTileDict - 2 * kFarReach - 1) && len <= (uint64_t)kMaxRowLen) {
                     const int32_t a = mintid[(size_t)r];
@@ -356,13 +381,15 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             out.left_col.insert(out.left_col.end(), P.left_col.begin(), P.left_col.end());
             for (uint64_t len : P.left_len) out.left_ptr.push_back(out.left_ptr.back() + len);
             act.insert(act.end(), P.act.begin(), P.act.end());
+            out.pair_row.insert(out.pair_row.end(), P.pair_row.begin(), P.pair_row.end());
+            out.pair_tid.insert(out.pair_tid.end(), P.pair_tid.begin(), P.pair_tid.end());
             P = Part();
         }
     }
     const int64_t n_act = (int64_t)act.size();
     // Sort granularity in tid space.  A tile's dictionary must hold a block's tid range plus the rows' reach, so
     // blocks stay small; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
-    int32_t block = 512;
+    int32_t block = 256;                  // two neighbouring blocks plus the rows' reach fit one dictionary (2 x 256 + 2 x kFarReach < kTileDict)
     if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 900) block = v; }
     int dense_min = kDenseMin;
     if (const char *e = getenv("EMSAR_HIP_TILE_DENSE")) { int v = atoi(e); if (v >= 1 && v <= 64) dense_min = v; }
@@ -410,29 +437,54 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     // The sorted rows are cut into fragments of kFragRows rows; every fragment is cut into slices on its own.  The cut
     // points depend on the data only, so the layout is the same whatever the number of host threads that build it.
     // A row is FAR when it has an entry more than far_reach tids from its anchor and its slice still has room in a far
-    // block; such rows fill the slice from the top (block 0 = field 11, block 1 = field 10), the others from the bottom.
+    // block; such rows take the first lanes of the top fields (block 0 = field 11, block 1 = field 10), the others fill the rest.
     struct SliceTmp {
         int64_t begin = 0, end = 0;          // sorted-row range
         int32_t nmin = 0, nmax = -1;         // tid range of the entries that need dictionary slots by position (near entries)
         uint32_t n_norm = 0, n_far = 0, k = 0;
+        uint32_t m = 0, coo_n = 0;           // backward units (int4 per lane) and COO pairs the encoder will produce
         int64_t ents = 0;                    // stored entries (exported ones not counted)
         std::vector<int32_t> expl;           // distinct un-exported far tids (explicit dictionary slots), ascending
     };
     auto is_far = [&](int32_t t, int32_t anchor) { return (t > anchor ? t - anchor : anchor - t) > far_reach; };
-    // index (within the row) of the entry that would be exported, or -1
-    auto export_index = [&](uint32_t r) -> int64_t {
-        if (!far_export) return -1;
+    // index (within the row) of the first far entry, or -1
+    auto first_far = [&](uint32_t r) -> int64_t {
         const int32_t a = mintid[r];
         for (uint64_t q = row_ptr[r]; q < row_ptr[r + 1]; q++) if (is_far(col_idx[q], a)) return (int64_t)(q - row_ptr[r]);
         return -1;
     };
+    // Exporting pays for COLD far transcripts: one row here, one there.  A transcript that is the far hit of many rows (a highly
+    // expressed paralog) is better served by a dictionary slot -- the rows of a group that hit it share one theta gather and one
+    // flush atomic -- and its run in far_w is summed by one workgroup of the update kernel, one run after the other.  So the far
+    // hits are counted per transcript first, and only transcripts with at most kFarHot of them are exported.
+    std::vector<uint32_t> far_refs;
+    if (far_export) {
+        far_refs.assign((size_t)n_tx, 0);
+        std::vector<std::vector<uint32_t>> part((size_t)std::max(1, n_host));
+        const int np = par_ranges(n_act, [&](int t, int64_t lo, int64_t hi) {
+            auto &h = part[(size_t)t];
+            h.assign((size_t)n_tx, 0);
+            for (int64_t i = lo; i < hi; i++) { const uint32_t r = perm[(size_t)i]; const int64_t ex = first_far(r); if (ex >= 0) h[(size_t)col_idx[row_ptr[r] + (uint64_t)ex]]++; }
+        });
+        for (int t = 0; t < np; t++) for (int32_t x = 0; x < n_tx; x++) far_refs[(size_t)x] += part[(size_t)t][(size_t)x];
+    }
+    // index (within the row) of the entry that would be exported, or -1
+    auto export_index = [&](uint32_t r) -> int64_t {
+        if (!far_export) return -1;
+        const int64_t ex = first_far(r);
+        if (ex >= 0 && far_refs[(size_t)col_idx[row_ptr[r] + (uint64_t)ex]] > far_hot) return -1;
+        return ex;
+    };
     auto cut_slices = [&](int64_t range_begin, int64_t range_end, std::vector<SliceTmp> &dst) {
         std::vector<int32_t> stamp((size_t)n_tx, -1);
+        std::vector<uint32_t> colcnt((size_t)n_tx, 0);       // entries per transcript inside the current slice
+        std::vector<int32_t> touched;
         int32_t sid = 0;
         int64_t i = range_begin;
         while (i < range_end) {
             SliceTmp S;
             S.begin = i;
+            touched.clear();
             int32_t nmin = INT32_MAX, nmax = -1;
             std::vector<int32_t> row_expl;
             for (; i < range_end; i++) {
@@ -452,7 +504,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                     else { lo1 = std::min(lo1, t); hi1 = std::max(hi1, t); }
                 }
                 if (S.n_norm + S.n_far > 0) {
-                    const bool rows_full = n_norm1 + 64 * ((n_far1 + 63) / 64) > (uint32_t)kTileSliceRows;
+                    const bool rows_full = n_norm1 + n_far1 > (uint32_t)kTileSliceRows;
                     const bool ents_full = S.ents + stored > kSliceEntries;
                     const int64_t span = hi1 >= lo1 ? (int64_t)hi1 - lo1 + 1 : 0;
                     const bool dict_full = span + (int64_t)S.expl.size() + (int64_t)row_expl.size() > kTileDict;
@@ -462,8 +514,22 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 S.k = std::max<uint32_t>(S.k, (uint32_t)stored);
                 nmin = lo1; nmax = hi1;
                 for (int32_t t : row_expl) { stamp[(size_t)t] = sid; S.expl.push_back(t); }
+                for (uint64_t q = b; q < e; q++) {
+                    if (far_row && (int64_t)(q - b) == ex) continue;
+                    const int32_t t = col_idx[q];
+                    if (colcnt[(size_t)t]++ == 0) touched.push_back(t);
+                }
             }
             S.end = i;
+            {   // what the encoder will make of the slice's columns: segments of kSegRows rows, or COO pairs below dense_min
+                uint64_t nseg = 0, ncoo = 0;
+                for (int32_t t : touched) {
+                    const uint32_t c = colcnt[(size_t)t];
+                    if (c < (uint32_t)dense_min) ncoo += c; else nseg += (c + kSegRows - 1) / kSegRows;
+                    colcnt[(size_t)t] = 0;
+                }
+                S.m = (uint32_t)((nseg + 63) / 64); S.coo_n = (uint32_t)ncoo;
+            }
             S.nmin = nmin == INT32_MAX ? 0 : nmin; S.nmax = nmax;
             std::sort(S.expl.begin(), S.expl.end());
             dst.push_back(std::move(S));
@@ -494,46 +560,121 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     if (n_slices * kTileSliceRows >= ((int64_t)1 << 32)) return -1;
     const auto tp3 = t_now();
 
-    // ---- P2: chunks of equal work, groups inside a chunk ----
-    // work of a slice ~ the bytes it streams: k forward columns + one backward int4 per 11 entries (+ a fixed cost per slice)
-    auto work_of = [](const SliceTmp &S) { return (int64_t)S.k * 1024 + S.ents * 16 / kSegRows + 2048; };
+    // ---- P2: chunks of equal work (one workgroup each), groups inside a chunk, heavy slices first inside a group ----
+    // work of a slice in shader cycles, fitted to per-slice stamps of a pass over BASELINE config 3 (tools/chunk_times.py):
+    // c0 + ck per forward column + cm per backward unit (one int4 per lane) + cc per COO pair + cf per far block
     {
-        int64_t total = 0;
+        double c0 = 3500, ck = 700, cm = 1300, cc = 25, cf = 3000;
+        if (const char *e = getenv("EMSAR_HIP_COST")) { double v[5]; if (sscanf(e, "%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4) == 5) { c0 = v[0]; ck = v[1]; cm = v[2]; cc = v[3]; cf = v[4]; } }
+        auto work_of = [&](const SliceTmp &S) { return c0 + ck * S.k + cm * S.m + cc * S.coo_n + cf * (double)((S.n_far + 63) / 64); };
+        double total = 0;
         for (const auto &S : st) total += work_of(S);
         const int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(n_slices, n_wg_slots));
         std::vector<int32_t> stamp((size_t)n_tx, -1);
         int32_t gid = 0;
-        int64_t done = 0, s = 0;
+        // natural breaks: where a dictionary that started at the previous break is full (greedy, over all slices).  A chunk cut that
+        // falls just behind such a break would leave a sliver of the old dictionary at the head of the chunk -- a group of one or
+        // two slices on which most of the workgroup's waves wait -- so cuts within 10 % of a chunk's work of a break move onto it.
+        std::vector<uint8_t> is_break((size_t)n_slices + 1, 0);
+        {
+            int64_t g0 = 0;
+            while (g0 < n_slices) {
+                int32_t lo = INT32_MAX, hi = -1;
+                int64_t n_expl = 0, g1 = g0;
+                gid++;
+                for (; g1 < n_slices; g1++) {
+                    const SliceTmp &S = st[(size_t)g1];
+                    int32_t lo1 = lo, hi1 = hi;
+                    if (S.nmax >= S.nmin) { lo1 = std::min(lo1, S.nmin); hi1 = std::max(hi1, S.nmax); }
+                    int64_t add = 0;
+                    for (int32_t t : S.expl) if (stamp[(size_t)t] != gid) add++;
+                    if (g1 > g0 && (hi1 >= lo1 ? (int64_t)hi1 - lo1 + 1 : 0) + n_expl + add > kTileDict) break;
+                    lo = lo1; hi = hi1;
+                    for (int32_t t : S.expl) if (stamp[(size_t)t] != gid) { stamp[(size_t)t] = gid; n_expl++; }
+                }
+                is_break[(size_t)g1] = 1;
+                g0 = g1;
+            }
+        }
+        std::vector<double> prefix((size_t)n_slices + 1, 0.0);
+        for (int64_t i = 0; i < n_slices; i++) prefix[(size_t)i + 1] = prefix[(size_t)i] + work_of(st[(size_t)i]);
+        const double snap = 0.10 * total / (double)n_chunks;
+        // EMSAR_HIP_AGE_SKEW "a,b,c,d" (experiment): relative work of the chunks in each quarter of the chunk order.  All workgroups are
+        // resident at once and the hardware serves the oldest waves first: with equal shares the first quarter finishes well before
+        // the last (143 / 153 / 165 / 175 us measured on config 3).
+        double skew[4] = {1, 1, 1, 1};
+        if (const char *e = getenv("EMSAR_HIP_AGE_SKEW")) { double v[4]; if (sscanf(e, "%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0) for (int i = 0; i < 4; i++) skew[i] = v[i]; }
+        std::vector<double> cum((size_t)n_chunks + 1, 0.0);
+        for (int64_t c = 0; c < n_chunks; c++) cum[(size_t)c + 1] = cum[(size_t)c] + skew[(size_t)(c * 4 / n_chunks)];
+        int64_t s = 0;
         for (int64_t c = 0; c < n_chunks && s < n_slices; c++) {
-            // slices [s, e): up to the point where the running work reaches (c + 1) / n_chunks of the total; at least one slice
-            const int64_t target = total * (c + 1) / n_chunks;
-            int64_t e = s;
-            while (e < n_slices && (e == s || done + work_of(st[(size_t)e]) / 2 <= target) && (n_slices - e) > (n_chunks - 1 - c)) { done += work_of(st[(size_t)e]); e++; }
-            if (c == n_chunks - 1) while (e < n_slices) { done += work_of(st[(size_t)e]); e++; }
+            // slices [s, e): up to the point where the running work reaches its share of the total; at least one slice,
+            // and enough left for the chunks to come
+            const double target = total * cum[(size_t)c + 1] / cum[(size_t)n_chunks];
+            const int64_t e_max = n_slices - (n_chunks - 1 - c);            // leave one slice for each chunk to come
+            int64_t e = s + 1;
+            while (e < e_max && prefix[(size_t)e] + work_of(st[(size_t)e]) / 2 <= target) e++;
+            if (c == n_chunks - 1) e = n_slices;
+            else {
+                int64_t best = -1;
+                for (int64_t b = e; b > s && prefix[(size_t)e] - prefix[(size_t)b] <= snap; b--) if (is_break[(size_t)b]) { best = b; break; }
+                for (int64_t b = e + 1; b <= e_max && prefix[(size_t)b] - prefix[(size_t)e] <= snap; b++)
+                    if (is_break[(size_t)b]) { if (best < 0 || prefix[(size_t)b] - prefix[(size_t)e] < prefix[(size_t)e] - prefix[(size_t)best]) best = b; break; }
+                if (best > s) e = best;
+            }
             ChunkDesc C;
             C.group_begin = (uint32_t)out.groups.size();
-            // groups: consecutive slices while their near range plus the explicit far tids fit one dictionary
-            int64_t g0 = s;
-            while (g0 < e) {
+            // groups: consecutive slices whose near range plus explicit far tids fit one dictionary.  With sort blocks of 256
+            // transcripts a chunk that touches two neighbouring blocks usually still fits one (2 x 256 + 2 x kFarReach < kTileDict):
+            // most chunks are ONE group and their four waves never wait for each other before the chunk's end.  A chunk that does
+            // not fit is cut where its two parts carry equal work if both parts fit (a greedy cut can leave ONE long-row slice
+            // in a group of its own: one wave works for 70 us, three wait at the group's barrier), else greedily.
+            auto dict_need = [&](int64_t a0, int64_t a1) -> int64_t {          // slots the slices [a0, a1) need in one dictionary
+                int32_t lo = INT32_MAX, hi = -1;
+                int64_t n_expl = 0;
+                gid++;
+                for (int64_t i = a0; i < a1; i++) {
+                    const SliceTmp &S = st[(size_t)i];
+                    if (S.nmax >= S.nmin) { lo = std::min(lo, S.nmin); hi = std::max(hi, S.nmax); }
+                    for (int32_t t : S.expl) if (stamp[(size_t)t] != gid) { stamp[(size_t)t] = gid; n_expl++; }
+                }
+                return (hi >= lo ? (int64_t)hi - lo + 1 : 0) + n_expl;      // conservative: explicit tids inside the window counted too
+            };
+            std::vector<int64_t> cuts;                                        // group boundaries inside [s, e)
+            cuts.push_back(s);
+            if (dict_need(s, e) > kTileDict && e - s >= 2) {
+                double half = 0, acc = 0;
+                for (int64_t i = s; i < e; i++) half += work_of(st[(size_t)i]);
+                half /= 2;
+                int64_t mid = s + 1;
+                for (int64_t i = s; i < e - 1; i++) { acc += work_of(st[(size_t)i]); mid = i + 1; if (acc >= half) break; }
+                if (dict_need(s, mid) <= kTileDict && dict_need(mid, e) <= kTileDict) cuts.push_back(mid);
+                else {                                                        // greedy: as many slices as fit, again and again
+                    int64_t g0 = s;
+                    while (g0 < e) {
+                        int64_t g1 = g0 + 1;
+                        while (g1 < e && dict_need(g0, g1 + 1) <= kTileDict) g1++;
+                        if (g1 < e) cuts.push_back(g1);
+                        g0 = g1;
+                    }
+                }
+            }
+            cuts.push_back(e);
+            for (size_t ci = 0; ci + 1 < cuts.size(); ci++) {
+                const int64_t g0 = cuts[ci], g1 = cuts[ci + 1];
                 GroupDesc G;
                 std::memset(&G, 0, sizeof G);
                 int32_t lo = INT32_MAX, hi = -1;
                 std::vector<int32_t> expl;
-                int64_t g1 = g0;
-                for (; g1 < e; g1++) {
-                    const SliceTmp &S = st[(size_t)g1];
-                    int32_t lo1 = lo, hi1 = hi;
-                    if (S.nmax >= S.nmin) { lo1 = std::min(lo1, S.nmin); hi1 = std::max(hi1, S.nmax); }
-                    size_t add = 0;
-                    for (int32_t t : S.expl) if (stamp[(size_t)t] != gid) add++;
-                    const int64_t span = hi1 >= lo1 ? (int64_t)hi1 - lo1 + 1 : 0;
-                    if (g1 > g0 && span + (int64_t)(expl.size() + add) > kTileDict) break;
-                    lo = lo1; hi = hi1;
+                gid++;
+                for (int64_t i = g0; i < g1; i++) {
+                    const SliceTmp &S = st[(size_t)i];
+                    if (S.nmax >= S.nmin) { lo = std::min(lo, S.nmin); hi = std::max(hi, S.nmax); }
                     for (int32_t t : S.expl) if (stamp[(size_t)t] != gid) { stamp[(size_t)t] = gid; expl.push_back(t); }
                 }
                 // explicit far tids that fall inside the window after all need no slot of their own
                 std::sort(expl.begin(), expl.end());
-                if (hi < lo) { lo = expl.empty() ? 0 : expl[0]; hi = lo; }      // a group of rows with far entries only
+                if (hi < lo) { lo = expl.empty() ? 0 : expl[0]; hi = lo; }      // cannot happen (every row has its anchor), kept harmless
                 G.lo = lo;
                 G.near_n = (uint16_t)(hi - lo + 1);
                 G.far_off = (uint32_t)out.far_tid.size();
@@ -541,8 +682,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 G.far_n = (uint16_t)(out.far_tid.size() - G.far_off);
                 G.slice_begin = (uint32_t)g0; G.slice_end = (uint32_t)g1;
                 out.groups.push_back(G);
-                gid++;
-                g0 = g1;
+                // the waves take a group's slices in descriptor order: heaviest first, so that the group ends on its lightest slices
+                std::stable_sort(st.begin() + g0, st.begin() + g1, [&](const SliceTmp &x, const SliceTmp &y) { return work_of(x) > work_of(y); });
             }
             C.group_end = (uint32_t)out.groups.size();
             out.chunks.push_back(C);
@@ -572,7 +713,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         out.slot_row.resize((size_t)n_slices * kTileSliceRows);
         out.padded_slots = (int64_t)fk * kTileSliceRows;
     }
-    struct EncPart { u32_vec bwd; std::vector<uint32_t> coo; std::vector<std::pair<int32_t, uint32_t>> farp; int64_t tiled = 0, far = 0, exported = 0; };
+    struct EncPart { u32_vec bwd; std::vector<uint32_t> coo; std::vector<std::pair<int32_t, uint32_t>> farp; int64_t tiled = 0, far = 0, exported = 0; bool bad = false; };
     const int64_t n_groups = (int64_t)out.groups.size();
     const int n_parts = (int)std::max<int64_t>(1, std::min<int64_t>(n_groups, (int64_t)std::max(1, n_host) * 4));
     std::vector<EncPart> parts((size_t)n_parts);
@@ -596,6 +737,15 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 std::fill(slots, slots + kTileSliceRows, (int64_t)-1);
                 pairs.clear();
                 uint32_t n_norm = 0, n_far = 0;
+                // Rows with an exported entry sit in the first lanes of the top fields (block 0 = field 11, block 1 = field 10);
+                // the other rows fill the remaining positions in sorted order, the free lanes of a far field included.
+                const uint32_t far_total = S.n_far, far_b1 = far_total > 64 ? far_total - 64 : 0, far_b0 = far_total - far_b1;
+                auto far_base = [&](uint32_t blk) { return (uint32_t)kTileSliceRows - 64 * (blk + 1); };
+                auto norm_pos = [&](uint32_t i) {          // i-th row without an exported entry -> slice position
+                    if (far_b1 > 0 && i >= far_base(1)) i += far_b1;                     // skip the taken lanes of field 10 ...
+                    if (i >= far_base(0)) i += far_b0;                                   // ... and of field 11
+                    return i;
+                };
                 for (int64_t i = S.begin; i < S.end; i++) {
                     const uint32_t r = perm[(size_t)i];
                     const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
@@ -604,12 +754,12 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                     uint32_t p;
                     if (far_row) {
                         const uint32_t blk = n_far / 64, ln = n_far % 64;
-                        p = (uint32_t)kTileSliceRows - 64 * (blk + 1) + ln;
+                        p = far_base(blk) + ln;
                         const int32_t ft = col_idx[b + (uint64_t)ex];
                         out.far_blk_tid[((size_t)D.far_blk + blk) * 64 + ln] = ft;
                         P.farp.emplace_back(ft, (uint32_t)(((size_t)D.far_blk + blk) * 64 + ln));
                         n_far++; P.exported++;
-                    } else p = n_norm++;
+                    } else p = norm_pos(n_norm++);
                     slots[p] = (int64_t)r;
                     const uint32_t fl = p & 63u, fi = p >> 6;
                     uint32_t c = 0;
@@ -652,6 +802,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 const int64_t nseg = (int64_t)segs.size() / 4;
                 const int m = (int)((nseg + 63) / 64);
                 D.m = (uint16_t)m;
+                if ((uint32_t)m != S.m || D.coo_n != S.coo_n) P.bad = true;      // cut_slices counted the same columns: a mismatch is a builder bug
                 D.bwd_kib = (uint32_t)(P.bwd.size() / kSliceDwords);      // part-local
                 uint32_t empty[4] = {0, 0, 0, 0};                          // unused segment: zero column, padding rows
                 pack10(empty, 0, zero_id);
@@ -686,6 +837,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             cb[(size_t)pi + 1] = cb[(size_t)pi] + parts[(size_t)pi].coo.size();
             fp[(size_t)pi + 1] = fp[(size_t)pi] + parts[(size_t)pi].farp.size();
         }
+        for (const auto &P : parts) if (P.bad) return -5;
         if (bb[(size_t)n_parts] / kSliceDwords >= ((size_t)1 << 32) || cb[(size_t)n_parts] >= ((size_t)1 << 32) || fp[(size_t)n_parts] >= ((size_t)1 << 32)) return -1;
         out.bwd.resize(bb[(size_t)n_parts]);
         out.coo.resize(cb[(size_t)n_parts]);
@@ -713,13 +865,18 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         // exported entries by transcript: the parts in order are in slice order, a stable counting sort by tid keeps it
         out.far_ptr.assign((size_t)n_tx + 1, 0);
         for (const auto &P : parts) for (const auto &fe : P.farp) out.far_ptr[(size_t)fe.first + 1]++;
+        for (int32_t t : out.pair_tid) out.far_ptr[(size_t)t + 1]++;
+        if (fp[(size_t)n_parts] + out.pair_tid.size() >= ((size_t)1 << 32)) return -1;
         for (int32_t t = 0; t < n_tx; t++) out.far_ptr[(size_t)t + 1] += out.far_ptr[(size_t)t];
-        out.far_pos.resize(fp[(size_t)n_parts]);
+        out.n_exported = (int64_t)(fp[(size_t)n_parts] + out.pair_tid.size());
+        out.far_blk_dst.assign(out.far_blk_tid.size(), 0xFFFFFFFFu);
         std::vector<uint32_t> fillp(out.far_ptr.begin(), out.far_ptr.end() - 1);
-        for (const auto &P : parts) for (const auto &fe : P.farp) out.far_pos[fillp[(size_t)fe.first]++] = fe.second;
+        for (const auto &P : parts) for (const auto &fe : P.farp) out.far_blk_dst[fe.second] = fillp[(size_t)fe.first]++;
+        out.pair_dst.resize(out.pair_tid.size());                   // a transcript's run: its slices' entries in slice order, then its pairs
+        for (size_t i = 0; i < out.pair_tid.size(); i++) out.pair_dst[i] = fillp[(size_t)out.pair_tid[i]]++;
     }
-    if (dbg_t) fprintf(stderr, "build_tiled: classify %.0f ms, sort %.0f ms, slices %.0f ms, groups %.0f ms, encode %.0f ms on %d thread(s); %lld slices, %lld groups, %lld chunks, %lld exported far entries, %lld explicit\n",
-                       t_ms(tp0, tp1), t_ms(tp1, tp2), t_ms(tp2, tp3), t_ms(tp3, tp4), t_ms(tp4, t_now()), n_host, (long long)n_slices, (long long)n_groups,
+    if (dbg_t) fprintf(stderr, "build_tiled: classify %.0f ms, sort %.0f ms, slices %.0f ms, chunks + groups %.0f ms, encode %.0f ms on %d thread(s); %lld slices, %lld groups, %lld chunks, %lld exported far entries, %lld explicit\n",
+                       t_ms(tp0, tp1), t_ms(tp1, tp2), t_ms(tp2, tp3), t_ms(tp3, tp4), t_ms(tp4, t_now()), n_host, (long long)n_slices, (long long)out.groups.size(),
                        (long long)out.chunks.size(), (long long)out.exported_entries, (long long)out.far_entries);
     return check_tiled_extents(out);       // O(slices): no descriptor may point outside the arrays that are uploaded next
 }
@@ -742,16 +899,38 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
         if (x != y) return -2;
         seen[r] = 1;
     }
-    // exported entries: far_ptr / far_pos is the transpose of the far blocks
+    // exported entries: every (block, lane) with a tid owns exactly one place of far_w, inside the run of that transcript
     {
-        std::vector<uint8_t> hit(L.far_blk_tid.size(), 0);
-        for (int32_t t = 0; t < L.n_tx; t++)
-            for (uint32_t q = L.far_ptr[(size_t)t]; q < L.far_ptr[(size_t)t + 1]; q++) {
-                const uint32_t pos = L.far_pos[q];
-                if (pos >= L.far_blk_tid.size() || hit[pos] || L.far_blk_tid[pos] != t) return -11;
-                hit[pos] = 1;
-            }
-        for (size_t i = 0; i < hit.size(); i++) if (!hit[i] && L.far_blk_tid[i] >= 0) return -11;
+        std::vector<uint8_t> hit((size_t)L.n_exported, 0);
+        for (size_t i = 0; i < L.far_blk_tid.size(); i++) {
+            const int32_t t = L.far_blk_tid[i];
+            if (t < 0) continue;
+            const uint32_t d = L.far_blk_dst[i];
+            if (d < L.far_ptr[(size_t)t] || d >= L.far_ptr[(size_t)t + 1] || hit[d]) return -11;
+            hit[d] = 1;
+        }
+        for (size_t i = 0; i < L.pair_tid.size(); i++) {
+            const int32_t t = L.pair_tid[i];
+            const uint32_t d = L.pair_dst[i];
+            if (d < L.far_ptr[(size_t)t] || d >= L.far_ptr[(size_t)t + 1] || hit[d]) return -11;
+            hit[d] = 1;
+        }
+        for (uint8_t x : hit) if (!x) return -11;
+    }
+    for (size_t i = 0; i < L.pair_row.size(); i++) {
+        const int64_t r = L.pair_row[i];
+        int32_t pa = L.pair_tid[2 * i], pb = L.pair_tid[2 * i + 1];
+        if (pa > pb) std::swap(pa, pb);
+        auto same = [&](uint32_t o) {
+            if (row_ptr[o + 1] - row_ptr[o] != 2) return false;
+            int32_t x = col_idx[row_ptr[o]], y = col_idx[row_ptr[o] + 1];
+            if (x > y) std::swap(x, y);
+            return x == pa && y == pb;
+        };
+        if (L.merged) {
+            if (L.mem_ptr[(size_t)r + 1] == L.mem_ptr[(size_t)r]) return -13;
+            for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) { const uint32_t o = L.mem_row[(size_t)q]; if (seen[o] || !same(o)) return -13; seen[o] = 1; }
+        } else { if (seen[(size_t)r] || !same((uint32_t)r)) return -13; seen[(size_t)r] = 1; }
     }
     std::vector<int32_t> a, b;
     std::vector<uint32_t> pf, pb;

@@ -20,15 +20,20 @@ class Rsh(C.Structure):
                 ("name_index", C.c_void_p), ("set_index", C.c_void_p)]
 
 
+COLLAPSE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
+                          C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int32))
+
+
 class AlnOpts(C.Structure):
-    _fields_ = [("pe", C.c_int), ("strand", C.c_char), ("max_repeat", C.c_int), ("format", C.c_int)]
+    _fields_ = [("pe", C.c_int), ("strand", C.c_char), ("max_repeat", C.c_int), ("format", C.c_int),
+                ("collapse", C.c_void_p), ("collapse_user", C.c_void_p), ("collapse_batch_rows", C.c_int64)]
 
 
 class Counts(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("R", C.POINTER(C.c_int32)), ("n_frag", C.c_int32),
                 ("frag_counts", C.POINTER(C.c_int32)), ("total_reads", C.c_int64),
                 ("reads_seen", C.c_int64), ("reads_over_k", C.c_int64), ("reads_bad_fraglen", C.c_int64),
-                ("reads_discrepant", C.c_int64), ("reads_no_segment", C.c_int64), ("readlength", C.c_int32)]
+                ("reads_discrepant", C.c_int64), ("reads_no_segment", C.c_int64), ("readlength", C.c_int32), ("batch", C.c_void_p)]
 
 
 class Model(C.Structure):
@@ -122,11 +127,29 @@ class HostRsh:
         a = np.ascontiguousarray(sorted(tids), dtype=np.int32)
         return lib().emsar_rsh_row_of(self._p, a.ctypes.data_as(C.POINTER(C.c_int32)), len(a))
 
-    def count(self, aln_path, pe=0, strand="ns", max_repeat=100, fmt=0):
+    def count(self, aln_path, pe=0, strand="ns", max_repeat=100, fmt=0, collapse=None, collapse_batch_rows=0):
+        """collapse: optional callable (row_ptr u64[n+1], col_idx i32[nnz]) -> (row_ptr, col_idx, weight) of the unique rows --
+        the kept reads with two or more transcripts then reach the counts through it, in batches (emsar_aln_opts.collapse)."""
         s = C.c_char()
         if lib().emsar_set_strand(strand.encode(), pe, C.byref(s)) != 0:
             raise HostError("invalid strand type")
-        o = AlnOpts(pe, s.value, max_repeat, fmt)
+        o = AlnOpts(pe, s.value, max_repeat, fmt, None, None, collapse_batch_rows)
+        if collapse is not None:
+            def _cb(user, n_rows, n_tx, rp, ci, nu, rp_o, ci_o, w_o):
+                try:
+                    rp_a = np.ctypeslib.as_array(rp, shape=(n_rows + 1,)).copy()
+                    ci_a = np.ctypeslib.as_array(ci, shape=(max(int(rp_a[-1]), 1),))[:int(rp_a[-1])].copy()
+                    a, b, w = collapse(rp_a, ci_a)
+                    nu[0] = len(w)
+                    np.ctypeslib.as_array(rp_o, shape=(n_rows + 1,))[:len(a)] = a
+                    if len(b):
+                        np.ctypeslib.as_array(ci_o, shape=(max(int(rp_a[-1]), 1),))[:len(b)] = b
+                    np.ctypeslib.as_array(w_o, shape=(n_rows,))[:len(w)] = w
+                    return 0
+                except Exception:
+                    return -1
+            self._collapse_cb = COLLAPSE_FN(_cb)            # kept alive for the duration of the call
+            o.collapse = C.cast(self._collapse_cb, C.c_void_p)
         p = C.POINTER(Counts)()
         err = C.create_string_buffer(512)
         rc = lib().emsar_count_alignments(self._p, aln_path.encode(), C.byref(o), C.byref(p), err, 512)

@@ -22,13 +22,17 @@ def _built():
     _build.build_host()
 
 
-def _host(golden):
-    r = HL.HostRsh(os.path.join(golden.dir, "index.rsh"))
+def _count(golden, r, **kw):
     opts = golden.meta["opts"]
     k = int(opts[opts.index("-k") + 1]) if "-k" in opts else 100
     aln, fmt = aln_path(golden.dir)
     assert fmt == (2 if "-B" in opts else 1 if "-S" in opts else 0)
-    c = r.count(aln, pe=int("-P" in opts), fmt=fmt, max_repeat=k)
+    return r.count(aln, pe=int("-P" in opts), fmt=fmt, max_repeat=k, **kw)
+
+
+def _host(golden):
+    r = HL.HostRsh(os.path.join(golden.dir, "index.rsh"))
+    c = _count(golden, r)
     return r, c, r.model(c)
 
 
@@ -269,3 +273,26 @@ def test_line_reader_edge_cases(tmp_path):
     h = lib.emsar_lr_open(p.encode())
     assert lib.emsar_lr_next(h) is None
     lib.emsar_lr_close(h)
+
+
+@pytest.mark.parametrize("batch_rows", [0, 7])
+def test_collapse_hook_gives_the_per_read_counts(golden, batch_rows):
+    """emsar_aln_opts.collapse: the kept reads with two or more transcripts are gathered as read-level rows and counted through
+    a collapse function (on the GPU: emsar_hip_collapse_rows, emsar-hip --device-collapse) instead of one rsh lookup per read.
+    Here the function is the oracle's restatement of update_ReadCounts' merge; batches of 7 rows exercise the flushes in the
+    middle of a file.  Every count must equal the per-read path's -- on every fixture, all input formats, threads on."""
+    import oracle as O
+    r, c, m = _host(golden)
+    calls = []
+
+    def collapse(rp, ci):
+        calls.append(len(rp) - 1)
+        a, b, w, _ = O.collapse_rows(rp, ci)
+        return a, b, w
+
+    c2 = _count(golden, r, collapse=collapse, collapse_batch_rows=batch_rows)
+    assert (c2.R == c.R).all() and c2.total_reads == c.total_reads
+    assert (c2.frag_counts == c.frag_counts).all()
+    assert c2.stats == c.stats
+    if (c.R[r.n_tx:] > 0).any():
+        assert calls and (batch_rows == 0 or max(calls) <= batch_rows)

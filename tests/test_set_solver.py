@@ -120,3 +120,49 @@ def test_print_quantum_stopping_rules(dev, golden, set_mode):
         assert st_q.iters <= st_s.iters   # solve's pass counts vary from run to run
     golden.check_fpkm_parity(quick, "zero_cut set_mode=%d" % set_mode)
     assert np.all(np.abs(quick - strict) <= 1e-6 * np.abs(strict) + 5e-7)
+
+
+def test_newton_steps_reach_the_em_fixed_point_in_far_fewer_passes(dev):
+    """emsar_em_params.newton_after: resident sets that have not converged after 60 passes get safeguarded projected-Newton
+    steps (kernels_sets.hpp).  A family problem with counts drawn from the model (bench.py's time_to_mle at a tenth of the
+    size): the EM-only solve (newton_after < 0) needs tens of thousands of passes for its slowest set; with the Newton
+    steps the same stopping rule is met in well under a tenth of that, at the same likelihood and the same fitted rates,
+    and exact zeros are KKT points (gradient <= 0)."""
+    rng = np.random.default_rng(11)
+    sizes = np.minimum(rng.zipf(1.6, size=6000), 60)
+    sizes = sizes[np.cumsum(sizes) <= 12000]
+    n_tx, rp, ci, _ = family_matrix([int(x) for x in sizes], rows_per_tid=3, seed=11, dup=0.0)
+    E = rng.uniform(0.5, 2.0, size=len(rp) - 1)
+    theta_true = np.where(rng.random(n_tx) < 0.3, 0.0, rng.lognormal(0.0, 2.0, size=n_tx))
+    R = rng.poisson(E * np.add.reduceat(theta_true[ci], rp[:-1].astype(np.int64))).astype(np.int32)
+    dev.upload_structure(n_tx, rp, ci, LAYOUT_TILED)
+    dev.upload_sample(R, E, None)
+    th_em, st_em = dev.solve(max_iter=150000, tol=1e-10, newton_after=-1)   # EM / SQUAREM only: its slowest sets may not even finish
+    th_nt, st_nt = dev.solve(max_iter=150000, tol=1e-10)                    # default: Newton steps after 60 passes
+    assert st_nt.converged == 1, (st_nt.set_passes_max, st_nt.sets_unconverged, st_nt.final_delta)
+    assert st_nt.sets_streamed == 0
+    assert st_em.set_passes_max > 20000, st_em.set_passes_max              # the problem is a slow one for the EM
+    assert st_nt.set_passes_max * 10 <= st_em.set_passes_max, (st_nt.set_passes_max, st_em.set_passes_max)
+    m = O.Csr(n_tx, rp, ci, R=R, E=E)
+    F_em, F_nt = m.loglik(th_em), m.loglik(th_nt)
+    assert F_nt >= F_em - 1e-11 * abs(F_em)                                # never below the EM's likelihood (it may be above: unfinished sets)
+    assert abs(st_nt.loglik - F_nt) <= 1e-10 * abs(F_nt)
+    assert np.all(np.abs(th_nt - th_em) <= 1e-4 * np.abs(th_em) + 1.5e-6)    # the EM's stragglers are still this far from the optimum
+    inside = (E > 0) & (R > 0)
+    S = lambda th: np.add.reduceat(th[ci], rp[:-1].astype(np.int64))[inside]
+    assert np.all(np.abs(S(th_nt) - S(th_em)) <= 1e-5 * S(th_em) + 1e-8)
+    # the oracle's own EM (CPU, SQUAREM) as the third opinion on the likelihood
+    th_o, st_o = m.em_solve(max_iter=150000, accel=1, tol=1e-10, n_threads=4)
+    assert F_nt >= m.loglik(th_o) - 1e-11 * abs(F_nt)
+    # a component the Newton step left at exactly 0 is a KKT point: d F / d theta_t = sum_c m_ct R_c / S_c - den_t <= 0
+    den = m.den()
+    Sall = np.add.reduceat(th_nt[ci], rp[:-1].astype(np.int64))
+    w = np.where((E > 0) & (Sall > 0), R / np.where(Sall > 0, Sall, 1.0), 0.0)
+    grad = np.zeros(n_tx)
+    np.add.at(grad, ci, np.repeat(w, np.diff(rp.astype(np.int64))))
+    z = (th_nt == 0) & (den > 0)
+    assert np.all(grad[z] <= den[z] * (1 + 1e-8))
+    # bit-reproducible: no atomics on the resident path, Newton steps included
+    th_nt2, st_nt2 = dev.solve(max_iter=400000, tol=1e-10)
+    np.testing.assert_array_equal(th_nt, th_nt2)
+    assert st_nt2.set_passes_sum == st_nt.set_passes_sum
