@@ -175,17 +175,34 @@ inline FarList far_list(const emsar_hip_ctx *ctx) {
 int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, double *ll_out, bool rows_only = false /* the folded rows' likelihood terms are added by the caller */) {
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
         const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
-        if (ctx->n_chunks > 0 || ctx->n_pairs > 0) {
-            const int64_t pair_wgs = std::min<int64_t>((ctx->n_pairs + kTiledThreads - 1) / kTiledThreads, ctx->n_wg_slots);
-            dim3 grid((unsigned)std::max<int64_t>(ctx->n_chunks, pair_wgs)), block(kTiledThreads);
-            const TiledArgs A{(int)ctx->n_chunks, ctx->d_chunks, ctx->d_groups, ctx->d_slices, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_far_blk, ctx->d_far_dst,
-                              ctx->d_far_w, ctx->d_wgt, ctx->d_rowval, ctx->n_pairs, ctx->d_pair_tid, ctx->d_pair_dst, ctx->d_pair_wgt,
-                              ctx->d_pair_val, ctx->d_stamps};
+        const bool with_pairs = ctx->n_pairs > 0;
+        if (with_pairs) {
+            HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
+        }
+        if (ctx->n_chunks > 0) {
+            dim3 grid((unsigned)ctx->n_chunks), block(kTiledThreads);
+            const TiledArgs A{ctx->d_chunks, ctx->d_groups, ctx->d_slices, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_far_blk, ctx->d_far_dst,
+                              ctx->d_far_w, ctx->d_wgt, ctx->d_rowval, ctx->d_stamps};
 #define LAUNCH_T(WT, MD) hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, A, theta, acc, ll_out)
             if (mode == MODE_SCATTER) LAUNCH_T(false, MODE_SCATTER);
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
             else { if (mode == MODE_EM_LL) LAUNCH_T(false, MODE_EM_LL); else LAUNCH_T(false, MODE_EM); }
 #undef LAUNCH_T
+        }
+        // the pairs on a side stream, next to the pass kernel (both only read theta; they write disjoint places of far_w).  Submitted AFTER
+        // the pass kernel: its workgroups own every VGPR of the CUs they sit on, so the pairs run where chunks have finished (the tail)
+        // -- launched first, the pairs' resident workgroups kept a quarter of the chunks off the CUs for 125 us.
+        if (with_pairs) {
+            const dim3 pg((unsigned)std::min<int64_t>((ctx->n_pairs + 255) / 256, 2048)), pb(256);
+#define LAUNCH_P(WT, MD) hipLaunchKernelGGL((k_pass_pairs<WT, MD>), pg, pb, 0, ctx->side[0], ctx->n_pairs, ctx->d_pair_tid, ctx->d_pair_dst, \
+                                           ctx->d_pair_wgt, ctx->d_pair_val, theta, ctx->d_far_w, ll_out)
+            if (mode == MODE_SCATTER) LAUNCH_P(false, MODE_SCATTER);
+            else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_P(true, MODE_EM_LL); else LAUNCH_P(true, MODE_EM); }
+            else { if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM); }
+#undef LAUNCH_P
+            HIPCHK(hipEventRecord(ctx->ev_join[0], ctx->side[0]));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
         }
         if (ctx->n_left > 0) {   // rows too long for a slice: generic CSR kernel on the leftover
             dim3 grid((unsigned)std::min<int64_t>((ctx->n_left + 255) / 256, 8192)), block(256);
@@ -525,11 +542,23 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
             HIPCHK(up((void **)&ctx->d_far, L.far_tid.data(), L.far_tid.size() * 4));
             HIPCHK(up((void **)&ctx->d_far_blk, L.far_blk_tid.data(), L.far_blk_tid.size() * 4));
             HIPCHK(up((void **)&ctx->d_far_ptr, L.far_ptr.data(), L.far_ptr.size() * 4));
-            HIPCHK(up((void **)&ctx->d_far_dst, L.far_blk_dst.data(), L.far_blk_dst.size() * 4));
+            {   // the layout lists the exported entries by transcript (far_ptr / far_src); the kernels want the inverse: for every far
+                // row of a slice and for both entries of a pair, its entry's place in that order
+                const size_t nb = L.far_blk_tid.size();
+                std::vector<uint32_t> blk_dst(nb, 0xFFFFFFFFu), pair_dst(L.pair_tid.size(), 0xFFFFFFFFu);
+                for (int32_t t = 0; t < n_tx; t++)
+                    for (uint32_t q = L.far_ptr[(size_t)t]; q < L.far_ptr[(size_t)t + 1]; q++) {
+                        const uint32_t x = L.far_src[q];
+                        if (x < nb) blk_dst[x] = q;
+                        else { const size_t i = x - nb; pair_dst[2 * i + (L.pair_tid[2 * i] == t ? 0 : 1)] = q; }
+                    }
+                HIPCHK(up((void **)&ctx->d_far_dst, blk_dst.data(), blk_dst.size() * 4));
+                HIPCHK(up((void **)&ctx->d_pair_dst, pair_dst.data(), pair_dst.size() * 4));
+            }
             HIPCHK(up((void **)&ctx->d_pair_tid, L.pair_tid.data(), L.pair_tid.size() * 4));
-            HIPCHK(up((void **)&ctx->d_pair_dst, L.pair_dst.data(), L.pair_dst.size() * 4));
-            HIPCHK(hipMalloc(&ctx->d_far_w, std::max<size_t>((size_t)L.n_exported, 2) * 8));
-            HIPCHK(hipMemset(ctx->d_far_w, 0, std::max<size_t>((size_t)L.n_exported, 2) * 8));
+            const size_t n_far_w = std::max<size_t>((size_t)L.n_exported, 2);
+            HIPCHK(hipMalloc(&ctx->d_far_w, n_far_w * 8));
+            HIPCHK(hipMemset(ctx->d_far_w, 0, n_far_w * 8));
             HIPCHK(up((void **)&ctx->d_left_ptr, L.left_ptr.data(), L.left_ptr.size() * 8));
             HIPCHK(up((void **)&ctx->d_left_col, L.left_col.data(), L.left_col.size() * 4));
             HIPCHK(hipMalloc(&ctx->d_u, T * 8));
@@ -545,7 +574,7 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
             ctx->tl_far_entries = L.far_entries + L.n_exported;
             emsar::u32_vec().swap(L.fwd); emsar::u32_vec().swap(L.bwd); std::vector<uint32_t>().swap(L.coo);
             std::vector<int32_t>().swap(L.left_col); std::vector<int32_t>().swap(L.far_blk_tid);
-            std::vector<uint32_t>().swap(L.far_blk_dst); std::vector<uint32_t>().swap(L.far_ptr);
+            std::vector<uint32_t>().swap(L.far_src); std::vector<uint32_t>().swap(L.far_ptr);
             const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
 #define SETLDS_T(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             SETLDS_T(false, MODE_EM); SETLDS_T(false, MODE_EM_LL); SETLDS_T(true, MODE_EM); SETLDS_T(true, MODE_EM_LL); SETLDS_T(false, MODE_SCATTER);
@@ -1022,7 +1051,7 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
             info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries + L.n_exported; info_out->window = emsar::kTileDict;
             info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 +
                                               (int64_t)L.far_tid.size() * 4 + (int64_t)L.slices.size() * 32 + (int64_t)L.groups.size() * 32 +
-                                              (int64_t)L.far_blk_tid.size() * 8 + L.n_exported * 16 + (int64_t)L.left_col.size() * 4;
+                                              (int64_t)L.far_blk_tid.size() * 12 + L.n_exported * 12 + (int64_t)L.pair_tid.size() * 4 + (int64_t)L.left_col.size() * 4;
             info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
         }
         return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;

@@ -193,17 +193,14 @@ __device__ __forceinline__ double sum_log_rows(const double (&S)[N]) {
 // loaded and flushed once per group (tens of slices), not once per 4 slices.
 // ------------------------------------------------------------------------------------------------
 struct TiledArgs {
-    int n_chunks;                   // workgroups beyond this only take pairs (a matrix of single-transcript rows and pairs has no chunk)
     const emsar::ChunkDesc *chunks; const emsar::GroupDesc *groups; const emsar::SliceDesc *slices;
     const uint32_t *fwd, *bwd, *coo;
     const int32_t *far_dict;        // explicit dictionary far lists
     const int32_t *far_blk_tid;     // exported far entries: [block][64] far tid (-1 = none)
     const uint32_t *far_blk_dst;    //                       [block][64] place of the row's weight in far_w (0xFFFFFFFF = none)
-    double *far_w;                  // weights of the rows with an exported entry, in transcript order
+    double *far_w;                  // weights of the rows with an exported entry, one per exported ENTRY, in transcript order
     const int32_t *wgt;             // per row slot (WEIGHTED)
     const double *rowval;           // per row slot (MODE_SCATTER)
-    // pairs: rows of two transcripts far from each other (layout_tiled.hpp): tids [2 n], places in far_w [2 n], weights / scatter values [n]
-    int64_t n_pairs; const int32_t *pair_tid; const uint32_t *pair_dst; const int32_t *pair_wgt; const double *pair_val;
     unsigned long long *stamps;     // diagnostic runs only (emsar_hip_debug_chunk_times), else null: per wave {start, end (100 MHz
                                     // clock), cycles spent inside slices, slices processed}, then one cycle count per slice;
                                     // read by nobody else
@@ -225,8 +222,9 @@ __device__ __forceinline__ void slice_head(const TiledArgs &P, const emsar::Slic
     if (MODE == MODE_SCATTER) return;
     const int k = __builtin_amdgcn_readfirstlane((int)D.k), nf = __builtin_amdgcn_readfirstlane((int)D.nf);
     const unsigned far_blk = __builtin_amdgcn_readfirstlane(D.far_blk);
-    if (nf > 0) ft0 = __builtin_nontemporal_load(&P.far_blk_tid[(size_t)far_blk * 64 + lane]);
-    if (nf > 1) ft1 = __builtin_nontemporal_load(&P.far_blk_tid[(size_t)(far_blk + 1) * 64 + lane]);
+    const int32_t *fb = P.far_blk_tid + (size_t)far_blk * 64;            // wave-uniform base, the lane adds 4 bytes of its own
+    if (nf > 0) ft0 = __builtin_nontemporal_load(fb + lane);
+    if (nf > 1) ft1 = __builtin_nontemporal_load(fb + 64 + lane);
     const int4 *e = reinterpret_cast<const int4 *>(P.fwd) + (size_t)__builtin_amdgcn_readfirstlane(D.fwd_kib) * 64;
     load8_clamped(A, e, lane, k < 8 ? k : 8);
 }
@@ -246,7 +244,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
     const unsigned th_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(th_w));
     const unsigned ws_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(w_s));
     if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;      // padding row of this wave's slices
-    const emsar::ChunkDesc C = (int)blockIdx.x < P.n_chunks ? P.chunks[blockIdx.x] : emsar::ChunkDesc{0u, 0u};
+    const emsar::ChunkDesc C = P.chunks[blockIdx.x];
     double ll = 0.0;
     const bool stamped = P.stamps != nullptr;                     // uniform; the timed runs never take these branches
     unsigned long long t_begin = 0, t_slices = 0, n_done = 0, t_ph[4] = {0, 0, 0, 0};   // phases: issue, E, w + next-slice issue, M
@@ -258,6 +256,13 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
     for (unsigned g = C.group_begin; g < C.group_end; g++) {
         const emsar::GroupDesc G = P.groups[g];
         const int near_n = (int)G.near_n, nd = near_n + (int)G.far_n;
+        // the wave's first slice (the first four slices are dealt, the rest come from the group's counter in LDS): its loads leave
+        // before the dictionary is fetched, not after the barrier behind it
+        unsigned s = G.slice_begin + (unsigned)wave;                       // wave-uniform
+        emsar::SliceDesc D;
+        int4 A[8];
+        int ft0 = -1, ft1 = -1;
+        if (s < G.slice_end) { D = P.slices[s]; slice_head<MODE>(P, D, ulane, A, ft0, ft1); }
         // ---- dictionary into LDS (slot nd is the zero slot) ----
         for (int d = threadIdx.x; d <= nd; d += kTiledThreads) {
             double v = 0.0;
@@ -272,11 +277,6 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
         // The wave's slices, software-pipelined: while slice s is in its M-step (LDS only), the forward columns and far tids of
         // the wave's NEXT slice are already on their way into the registers the E-step has just released -- a wave that asked for
         // its loads only when it needed them spent a third of its life waiting for HBM with the LDS pipe idle.
-        unsigned s = G.slice_begin + (unsigned)wave;                       // wave-uniform; the first four slices are dealt, the rest
-        emsar::SliceDesc D;                                                // come from the group's counter in LDS
-        int4 A[8];
-        int ft0 = -1, ft1 = -1;
-        if (s < G.slice_end) { D = P.slices[s]; slice_head<MODE>(P, D, ulane, A, ft0, ft1); }
         while (s < G.slice_end) {
             const unsigned long long ts0 = stamped ? stamp_now() : 0ull;
 #ifdef EMSAR_TILED_PRIO
@@ -303,19 +303,28 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
                 if (ft0 >= 0) fv0 = theta[ft0];
                 if (ft1 >= 0) fv1 = theta[ft1];
             }
-            // requested now (in the registers the far tids have just left), needed at the end of the E-step -- asked for only
-            // then, each far block cost the wave a full trip to HBM
+            // where the far rows' weights go (their entries' places in transcript order): requested now, in the registers the far
+            // tids have just left, needed right after the E-step
             unsigned dst0 = 0xFFFFFFFFu, dst1 = 0xFFFFFFFFu;
-            if (nf > 0) dst0 = __builtin_nontemporal_load(&P.far_blk_dst[(size_t)far_blk * 64 + lane]);
-            if (nf > 1) dst1 = __builtin_nontemporal_load(&P.far_blk_dst[(size_t)(far_blk + 1) * 64 + lane]);
+            const uint32_t *fd = P.far_blk_dst + (size_t)far_blk * 64;     // wave-uniform base
+            if (nf > 0) dst0 = __builtin_nontemporal_load(fd + ulane);
+            if (nf > 1) dst1 = __builtin_nontemporal_load(fd + 64 + ulane);
+            // the wave's next slice: its number from the group's counter and its descriptor (a scalar load, a trip to L2) are asked
+            // for now and used after the E-step
+            unsigned nx = 0;
+            if (lane == 0) nx = __hip_atomic_fetch_add(&next_slice, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned sn = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
+            emsar::SliceDesc Dn = D;
+            if (sn < G.slice_end) Dn = P.slices[sn];
             const unsigned long long tp1 = stamped ? stamp_now() : 0ull;
             // ---- E: row sums of the slice's 768 rows ----
             // row i of lane l is slot 64*i + l of the slice: the lanes of one gather hold consecutive sorted rows
-            const size_t slot0 = (size_t)s * emsar::kTileSliceRows + lane;
+            const size_t slot_base = (size_t)s * emsar::kTileSliceRows;    // wave-uniform; row i of this lane is slot slot_base + 64 i + lane
             double w[kRPL];
             if (MODE == MODE_SCATTER) {
+                const double *rv = P.rowval + slot_base;
 #pragma unroll
-                for (int i = 0; i < kRPL; i++) w[i] = P.rowval[slot0 + 64 * i];
+                for (int i = 0; i < kRPL; i++) w[i] = rv[64u * (unsigned)i + ulane];
             } else {
                 double S[kRPL];
 #pragma unroll
@@ -330,13 +339,14 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
 #pragma unroll
                 for (int i = 0; i < kRPL; i++) r[i] = 1.0;
                 if (WEIGHTED) {
+                    const int32_t *wg = P.wgt + slot_base;
 #pragma unroll
-                    for (int i = 0; i < kRPL; i++) r[i] = (double)__builtin_nontemporal_load(&P.wgt[slot0 + 64 * i]);
+                    for (int i = 0; i < kRPL; i++) r[i] = (double)__builtin_nontemporal_load(wg + (64u * (unsigned)i + ulane));
                 }
 #pragma unroll
                 for (int i = 0; i < kRPL; i++) {
                     bool live = (S[i] > 0.0) && (r[i] > 0.0);
-                    w[i] = live ? r[i] / S[i] : 0.0;
+                    w[i] = live ? r[i] * fast_rcp(S[i]) : 0.0;      // v_rcp_f64 + two Newton steps: 5 instructions instead of the IEEE division's dozen
                     if (MODE == MODE_EM_LL && WEIGHTED && live) ll += r[i] * log(S[i]);
                 }
                 if (MODE == MODE_EM_LL && !WEIGHTED) ll += sum_log_rows(S);
@@ -344,6 +354,14 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
             const unsigned long long tp2 = stamped ? stamp_now() : 0ull;
 #pragma unroll
             for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = w[i];
+            // The far fields' weights go straight to their entries' places in transcript order (the update kernels then add up
+            // contiguous runs).  The place of these scattered stores in the program matters: a wave's loads and stores complete in
+            // issue order (one vmcnt counter), so they stand in front of every load issued after them.  Here, the next loads
+            // waited for are the M-step's reloads of backward segments, eight segments of LDS work away.  At the END of the slice
+            // they stood in front of the next slice's first wait (4.8 k cycles per slice); coalesced stores to a [block][64] array
+            // that the update kernels gather from cost nothing here but 35 us per pass there.
+            if (dst0 != 0xFFFFFFFFu) P.far_w[dst0] = w[kRPL - 1];
+            if (dst1 != 0xFFFFFFFFu) P.far_w[dst1] = w[kRPL - 2];
             // the M-step below reads rows written by OTHER lanes of this same wave: DS operations of one wave execute in
             // order, so only the compiler has to be kept from moving the reads up
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -351,12 +369,8 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- the wave's next slice: its number from the group's counter, its first loads into the forward registers (the row weights are
             // in LDS by now: the registers of both are free) ----
-            unsigned nx = 0;
-            if (lane == 0) nx = __hip_atomic_fetch_add(&next_slice, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const unsigned sn = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
-            emsar::SliceDesc Dn = D;
             int ftn0 = -1, ftn1 = -1;
-            if (sn < G.slice_end) { Dn = P.slices[sn]; slice_head<MODE>(P, Dn, ulane, A, ftn0, ftn1); }
+            if (sn < G.slice_end) slice_head<MODE>(P, Dn, ulane, A, ftn0, ftn1);
             const unsigned long long tp3 = stamped ? stamp_now() : 0ull;
             // ---- M: column sums over the same 768 rows, through the slice's transposed index ----
             unsigned cur = 0xFFFFFFFFu;
@@ -367,17 +381,12 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
                 bwd_sum_regs<EMSAR_M_BATCH>(B, n0, ws_base, acc_w, cur, part);
             }
             if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
-            for (unsigned q = lane; q < coo_n; q += 64) {
-                const unsigned p = __builtin_nontemporal_load(&P.coo[coo_base + q]);
+            const uint32_t *cb = P.coo + coo_base;                         // wave-uniform base
+            for (unsigned q = ulane; q < coo_n; q += 64) {
+                const unsigned p = __builtin_nontemporal_load(cb + q);
                 const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
                 if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + ((p >> 16) << 3)), v);
             }
-            // The far rows' weights leave for far_w only now, read back from LDS.  A wave's loads and stores complete in issue order
-            // (one vmcnt counter): scattered 8-byte stores issued before the M-step would stand in front of every load the M-step
-            // waits for (its reloads of backward segments); here the next loads waited for are the next slice's forward columns,
-            // requested before these stores.
-            if (dst0 != 0xFFFFFFFFu) P.far_w[dst0] = w_s[64 * (kRPL - 1) + lane];
-            if (dst1 != 0xFFFFFFFFu) P.far_w[dst1] = w_s[64 * (kRPL - 2) + lane];
             // the next slice's E-step overwrites w_s: again only the compiler needs telling
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -403,20 +412,6 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
         // a thread rewrites only the dictionary slots it has just flushed (same d -> thread mapping), next_slice is rewritten
         // by thread 0 and read by nobody before the next barrier: no barrier needed here
     }
-    // ---- the pairs: every workgroup takes its share after its chunk (two theta gathers, one division, two stores per row) ----
-    for (int64_t i = (int64_t)blockIdx.x * kTiledThreads + threadIdx.x; i < P.n_pairs; i += (int64_t)gridDim.x * kTiledThreads) {
-        double w;
-        if (MODE == MODE_SCATTER) w = P.pair_val[i];
-        else {
-            const double S = theta[P.pair_tid[2 * i]] + theta[P.pair_tid[2 * i + 1]];
-            const double r = WEIGHTED ? (double)P.pair_wgt[i] : 1.0;
-            const bool live = (S > 0.0) && (r > 0.0);
-            w = live ? r / S : 0.0;
-            if (MODE == MODE_EM_LL && live) ll += r * log(S);
-        }
-        P.far_w[P.pair_dst[2 * i]] = w;
-        P.far_w[P.pair_dst[2 * i + 1]] = w;
-    }
     if (stamped && lane == 0) {
         unsigned long long *o = P.stamps + ((size_t)blockIdx.x * emsar::kTileWaves + wave) * 8;
         o[0] = t_begin; o[1] = stamp_real(); o[2] = t_slices; o[3] = n_done;
@@ -424,6 +419,36 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const TiledArgs
     }
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);
+        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pass_pairs: the rows of two transcripts far from each other (layout_tiled.hpp) -- two theta gathers, one reciprocal and two
+// stores per row, w = R / (theta_a + theta_b) to the places of the row's two entries in far_w.  Runs on a side stream next to
+// k_pass_tiled (a chain of dependent trips to memory per thread: inside the pass kernel it held a workgroup's slot for 5 us).
+// ------------------------------------------------------------------------------------------------
+template <bool WEIGHTED, int MODE>
+__global__ __launch_bounds__(256) void k_pass_pairs(int64_t n_pairs, const int32_t *__restrict__ pair_tid, const uint32_t *__restrict__ pair_dst,
+                                                    const int32_t *__restrict__ pair_wgt, const double *__restrict__ pair_val,
+                                                    const double *__restrict__ theta, double *__restrict__ far_w, double *__restrict__ ll_out) {
+    __shared__ double red[4];
+    double ll = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_pairs; i += (int64_t)gridDim.x * 256) {
+        double w;
+        if (MODE == MODE_SCATTER) w = pair_val[i];
+        else {
+            const double S = theta[pair_tid[2 * i]] + theta[pair_tid[2 * i + 1]];
+            const double r = WEIGHTED ? (double)pair_wgt[i] : 1.0;
+            const bool live = (S > 0.0) && (r > 0.0);
+            w = live ? r * fast_rcp(S) : 0.0;
+            if (MODE == MODE_EM_LL && live) ll += r * log(S);
+        }
+        far_w[pair_dst[2 * i]] = w;
+        far_w[pair_dst[2 * i + 1]] = w;
+    }
+    if (MODE == MODE_EM_LL) {
+        double t = block_sum<256>(ll, red);
         if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
     }
 }

@@ -13,9 +13,9 @@ __global__ void k_fill_start(int n, const double *__restrict__ den, double *__re
 }
 
 // Exported far entries of the TILED layout (layout_tiled.hpp): the pass kernel stores the weight w_r of every row with an
-// exported entry at that entry's place in far_w, which lists the exported entries in transcript order; the M-step sum of
-// transcript t is acc_t + the contiguous run far_w[ptr[t] .. ptr[t+1]) -- summed here in fixed order instead of one scattered
-// atomic per entry in the pass kernel.  ptr == nullptr: no such entries.
+// exported entry (and of every pair, twice) at that entry's place in far_w, which lists the exported entries in transcript
+// order; the M-step sum of transcript t is acc_t + the contiguous run far_w[ptr[t] .. ptr[t+1]) -- summed here in fixed order
+// instead of one scattered atomic per entry in the pass kernel.  ptr == nullptr: no such entries.
 struct FarList { const uint32_t *ptr; const double *w; };
 __device__ __forceinline__ double far_sum(const FarList &F, int t) {
     double s = 0.0;
@@ -24,7 +24,8 @@ __device__ __forceinline__ double far_sum(const FarList &F, int t) {
 }
 // The same sums for the 256 consecutive transcripts [t_base, t_base + 256) of one workgroup iteration: their runs are one
 // contiguous stretch of far_w, which the workgroup copies into LDS with coalesced loads (one round trip to memory for the whole
-// stretch -- far_w was written by the pass kernel, possibly on another XCD, so every line is a miss) before the runs are added up.
+// stretch -- far_w was written by the pass kernel, possibly on another XCD, so every line is a miss, and a thread that chased its
+// own run entry by entry took 0.5 ms) before the runs are added up.
 // A run of up to kFarSerial entries is summed by its own thread, in ascending order.  Longer runs (a transcript that is the far
 // hit of thousands of rows: summed by one thread, 2000 entries took 80 us) are summed by a wavefront each: lane i takes entries
 // i, i + 64, ... and the 64 partial sums go through a fixed butterfly -- another order of additions than far_sum's, but the

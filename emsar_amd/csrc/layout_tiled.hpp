@@ -20,9 +20,9 @@
 //     atomics.  The first far entry of a row is therefore EXPORTED: the row is placed in one of the last fields of its slice
 //     (field 11, then 10: at most 128 such rows per slice), the far tid goes to a per-slice FAR BLOCK of 64 tids that the
 //     lanes of the wave gather straight from theta into the register that holds that field's row sum, and the row's weight
-//     w_r is stored to far_w[far_dst[block][lane]]: far_w lists the exported entries in TRANSCRIPT order, so the update kernels
-//     add the contiguous run far_w[far_ptr[t] .. far_ptr[t+1]) to acc_t -- no dictionary slot, no atomic, no gather, fixed
-//     summation order.
+//     w_r is stored to far_w[block][lane] (one coalesced 512-byte store per block); the update kernels add, for transcript t,
+//     far_w[far_src[q]] over its exported entries q in [far_ptr[t], far_ptr[t+1]) -- a CSR by transcript whose values are
+//     gathered through far_src: no dictionary slot, no atomic, fixed summation order.
 //     Further far entries of the same row (rare) keep explicit dictionary slots (the group's far list);
 //     A row of exactly TWO transcripts that are far from each other (a read with one hit here and one in another family) is a
 //     PAIR: it never enters a slice; the pass kernel computes w = R / (theta_a + theta_b) from two gathers and stores it to far_w
@@ -126,13 +126,12 @@ struct TiledLayout {
     std::vector<int32_t> far_tid;       // explicit dictionary far lists of the groups
     // exported far entries
     std::vector<int32_t> far_blk_tid;   // [n_far_blocks][64]: far tid of the row in (block, lane), -1 = none
-    std::vector<uint32_t> far_blk_dst;  // [n_far_blocks][64]: where that row's weight goes in far_w (0xFFFFFFFF = none)
-    std::vector<uint32_t> far_ptr;      // [n_tx + 1]: exported entries by transcript: far_w[far_ptr[t] .. far_ptr[t+1])
-    int64_t n_exported = 0;             // = far_ptr[n_tx]
+    std::vector<uint32_t> far_ptr;      // [n_tx + 1]: exported entries by transcript: far_src[far_ptr[t] .. far_ptr[t+1])
+    std::vector<uint32_t> far_src;      // -> index into far_w: 64 block + lane for a slice's row, 64 n_far_blocks + i for pair i
+    int64_t n_exported = 0;             // = far_ptr[n_tx] = far_src.size()
     // pairs: rows of two transcripts far from each other, both entries exported
     std::vector<int64_t> pair_row;      // original row, or merged-row id when `merged`
     std::vector<int32_t> pair_tid;      // [2 n_pairs]
-    std::vector<uint32_t> pair_dst;     // [2 n_pairs] places in far_w
     // leftover rows (too long for a slice): plain CSR + original row ids
     std::vector<uint64_t> left_ptr;
     std::vector<int32_t> left_col;
@@ -172,8 +171,8 @@ inline void run_on_threads(int nt, F fn) {
 //             COO       dword reads [coo_off, coo_off + coo_n)
 //             far blocks [far_blk, far_blk + nf), nf <= kMaxFarBlocks, every tid in it -1 or inside [0, n_tx)
 //             row slots [768 i, 768 i + 768)   (weights, scatter values, slot_row)
-//   pairs     two tids inside [0, n_tx) and two places < n_exported each
-//   far_blk_dst  every entry < n_exported (the length of far_w) exactly where far_blk_tid holds a tid
+//   pairs     two tids inside [0, n_tx)
+//   far_src   every entry < 64 n_far_blocks + n_pairs (the length of far_w)
 // 0 = fine, else a negative code naming the first violated rule.
 inline int check_tiled_extents(const TiledLayout &L) {
     const uint64_t n_fwd = (uint64_t)L.fwd.size() / 4, n_bwd = (uint64_t)L.bwd.size() / 4;     // int4 units
@@ -198,17 +197,12 @@ inline int check_tiled_extents(const TiledLayout &L) {
     if ((uint64_t)L.slices.size() * kTileSliceRows != (uint64_t)L.slot_row.size()) return -30;
     if (L.far_ptr.size() != (size_t)L.n_tx + 1 || L.far_ptr.front() != 0 || (int64_t)L.far_ptr.back() != L.n_exported) return -34;
     for (size_t t = 0; t + 1 < L.far_ptr.size(); t++) if (L.far_ptr[t] > L.far_ptr[t + 1]) return -34;
-    if (L.far_blk_dst.size() != L.far_blk_tid.size()) return -34;
-    for (size_t i = 0; i < L.far_blk_dst.size(); i++) {
-        const uint32_t d = L.far_blk_dst[i];
-        if ((d == 0xFFFFFFFFu) != (L.far_blk_tid[i] < 0)) return -34;
-        if (d != 0xFFFFFFFFu && (int64_t)d >= L.n_exported) return -34;
-    }
+    if ((int64_t)L.far_src.size() != L.n_exported) return -34;
+    for (uint32_t x : L.far_src) if ((uint64_t)x >= (uint64_t)L.far_blk_tid.size() + L.pair_row.size()) return -34;
     if (L.left_ptr.size() != L.left_row.size() + 1 || (L.left_ptr.empty() ? 0 : L.left_ptr.back()) != (uint64_t)L.left_col.size()) return -31;
     if (L.single_row.size() != L.single_tid.size()) return -32;
-    if (L.pair_tid.size() != 2 * L.pair_row.size() || L.pair_dst.size() != L.pair_tid.size()) return -35;
-    for (size_t i = 0; i < L.pair_tid.size(); i++)
-        if (L.pair_tid[i] < 0 || L.pair_tid[i] >= L.n_tx || (int64_t)L.pair_dst[i] >= L.n_exported) return -35;
+    if (L.pair_tid.size() != 2 * L.pair_row.size()) return -35;
+    for (size_t i = 0; i < L.pair_tid.size(); i++) if (L.pair_tid[i] < 0 || L.pair_tid[i] >= L.n_tx) return -35;
     return 0;
 }
 
@@ -869,12 +863,14 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         if (fp[(size_t)n_parts] + out.pair_tid.size() >= ((size_t)1 << 32)) return -1;
         for (int32_t t = 0; t < n_tx; t++) out.far_ptr[(size_t)t + 1] += out.far_ptr[(size_t)t];
         out.n_exported = (int64_t)(fp[(size_t)n_parts] + out.pair_tid.size());
-        out.far_blk_dst.assign(out.far_blk_tid.size(), 0xFFFFFFFFu);
+        if (out.far_blk_tid.size() + out.pair_row.size() >= ((size_t)1 << 32)) return -1;
+        out.far_src.resize((size_t)out.n_exported);                 // a transcript's run: its slices' entries in slice order, then its pairs
         std::vector<uint32_t> fillp(out.far_ptr.begin(), out.far_ptr.end() - 1);
-        for (const auto &P : parts) for (const auto &fe : P.farp) out.far_blk_dst[fe.second] = fillp[(size_t)fe.first]++;
-        out.pair_dst.resize(out.pair_tid.size());                   // a transcript's run: its slices' entries in slice order, then its pairs
-        for (size_t i = 0; i < out.pair_tid.size(); i++) out.pair_dst[i] = fillp[(size_t)out.pair_tid[i]]++;
+        for (const auto &P : parts) for (const auto &fe : P.farp) out.far_src[fillp[(size_t)fe.first]++] = fe.second;
+        const uint32_t pair_base = (uint32_t)out.far_blk_tid.size();
+        for (size_t i = 0; i < out.pair_tid.size(); i++) out.far_src[fillp[(size_t)out.pair_tid[i]]++] = pair_base + (uint32_t)(i / 2);
     }
+    if (const char *e = getenv("EMSAR_HIP_CHUNK_REVERSE")) if (atoi(e)) std::reverse(out.chunks.begin(), out.chunks.end());   // experiment: does a workgroup's speed follow its index or its chunk?
     if (dbg_t) fprintf(stderr, "build_tiled: classify %.0f ms, sort %.0f ms, slices %.0f ms, chunks + groups %.0f ms, encode %.0f ms on %d thread(s); %lld slices, %lld groups, %lld chunks, %lld exported far entries, %lld explicit\n",
                        t_ms(tp0, tp1), t_ms(tp1, tp2), t_ms(tp2, tp3), t_ms(tp3, tp4), t_ms(tp4, t_now()), n_host, (long long)n_slices, (long long)out.groups.size(),
                        (long long)out.chunks.size(), (long long)out.exported_entries, (long long)out.far_entries);
@@ -899,23 +895,23 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
         if (x != y) return -2;
         seen[r] = 1;
     }
-    // exported entries: every (block, lane) with a tid owns exactly one place of far_w, inside the run of that transcript
+    // exported entries: far_ptr / far_src is the transpose of the far blocks and the pairs -- every (block, lane) that holds a tid is
+    // named exactly once, in the run of that tid; every pair exactly twice, once in the run of each of its transcripts
     {
-        std::vector<uint8_t> hit((size_t)L.n_exported, 0);
-        for (size_t i = 0; i < L.far_blk_tid.size(); i++) {
-            const int32_t t = L.far_blk_tid[i];
-            if (t < 0) continue;
-            const uint32_t d = L.far_blk_dst[i];
-            if (d < L.far_ptr[(size_t)t] || d >= L.far_ptr[(size_t)t + 1] || hit[d]) return -11;
-            hit[d] = 1;
-        }
-        for (size_t i = 0; i < L.pair_tid.size(); i++) {
-            const int32_t t = L.pair_tid[i];
-            const uint32_t d = L.pair_dst[i];
-            if (d < L.far_ptr[(size_t)t] || d >= L.far_ptr[(size_t)t + 1] || hit[d]) return -11;
-            hit[d] = 1;
-        }
-        for (uint8_t x : hit) if (!x) return -11;
+        const size_t nb = L.far_blk_tid.size();
+        std::vector<uint8_t> hit(nb + L.pair_row.size(), 0);
+        for (int32_t t = 0; t < L.n_tx; t++)
+            for (uint32_t q = L.far_ptr[(size_t)t]; q < L.far_ptr[(size_t)t + 1]; q++) {
+                const uint32_t x = L.far_src[q];
+                if (x < nb) { if (hit[x] || L.far_blk_tid[x] != t) return -11; hit[x] = 1; }
+                else {
+                    const size_t i = x - nb;
+                    if (hit[x] >= 2 || (L.pair_tid[2 * i] != t && L.pair_tid[2 * i + 1] != t)) return -11;
+                    hit[x]++;
+                }
+            }
+        for (size_t i = 0; i < nb; i++) if ((hit[i] != 0) != (L.far_blk_tid[i] >= 0)) return -11;
+        for (size_t i = 0; i < L.pair_row.size(); i++) if (hit[nb + i] != 2) return -11;
     }
     for (size_t i = 0; i < L.pair_row.size(); i++) {
         const int64_t r = L.pair_row[i];

@@ -12,7 +12,7 @@ template <class T> static bool same_pod(const std::vector<T> &a, const std::vect
 static bool same_layout(const emsar::TiledLayout &a, const emsar::TiledLayout &b) {
     return same_pod(a.slices, b.slices) && same_pod(a.groups, b.groups) && same_pod(a.chunks, b.chunks) &&
            a.single_row == b.single_row && a.single_tid == b.single_tid && a.slot_row == b.slot_row && a.fwd == b.fwd && a.bwd == b.bwd &&
-           a.coo == b.coo && a.far_tid == b.far_tid && a.far_blk_tid == b.far_blk_tid && a.far_ptr == b.far_ptr && a.far_blk_dst == b.far_blk_dst && a.pair_row == b.pair_row && a.pair_tid == b.pair_tid && a.pair_dst == b.pair_dst &&
+           a.coo == b.coo && a.far_tid == b.far_tid && a.far_blk_tid == b.far_blk_tid && a.far_ptr == b.far_ptr && a.far_src == b.far_src && a.pair_row == b.pair_row && a.pair_tid == b.pair_tid &&
            a.left_ptr == b.left_ptr && a.left_col == b.left_col && a.left_row == b.left_row && a.mem_ptr == b.mem_ptr && a.mem_row == b.mem_row;
 }
 int main(int argc, char **argv) {
