@@ -141,7 +141,7 @@ def main():
                          "kernel": {1: "k_pass_csr", 3: tiled_kernel, 259: "k_pass_tiled"}[info["layout"]] + "+k_update",
                          "algorithmic_bytes_per_pass": bytes_pass, "stored_bytes_per_pass": info["stored_bytes_per_pass"],
                          "device_ms_per_pass": per_pass_s * 1e3},
-            "layout_stats": {k: info[k] for k in ("n_chunks", "n_groups", "n_slices", "padded_entries", "far_entries", "exported_entries", "window")},
+            "layout_stats": {k: info[k] for k in ("n_chunks", "n_slices", "padded_entries", "far_entries", "window")},
             "setup_s": {"generate": round(t_gen, 2), "upload_and_layout": round(t_up, 2)},
             "mass_conserved": ok,
         }

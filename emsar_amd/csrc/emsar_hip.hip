@@ -9,9 +9,8 @@
 // One pass is HBM-bound integer streaming plus FP64 adds: ~2 flop per nonzero -- no MFMA.
 // This file: the context, the launch logic (launch_pass, enqueue_cycles, the set solver's driver) and the C ABI.
 // Kernels (one translation unit, included below):
-//   kernels_tiled.hpp     k_pass_tiled                           the hot one: one workgroup per chunk of the TILED layout, a
-//                         dictionary of theta/acc in LDS per group of slices, 10-bit ids, per-slice transposed index,
-//                         exported far entries
+//   kernels_tiled.hpp     k_pass_tiled / k_pass_tiled_multi<2>   the hot ones: one workgroup per tile (or pair of tiles) of the
+//                         TILED layout, dictionary of theta/acc in LDS, 10-bit ids, per-slice transposed index
 //   kernels_csr.hpp       k_pass_csr                             the caller's CSR as it is (layout 1), leftover rows of TILED
 //   kernels_vector.hpp    k_update, k_update_p2/p3, k_sq_extrap_ll (SQUAREM extrapolation / acceptance on the device),
 //                         k_normalise, k_adj_euma, small reductions
@@ -43,6 +42,7 @@
 // ==================================================================================================
 // context
 // ==================================================================================================
+constexpr int64_t kPairMinTiles = 2048;   // 256 CUs x 4 resident workgroups x 2 tiles
 
 struct emsar_hip_ctx {
     int device = 0;
@@ -62,17 +62,12 @@ struct emsar_hip_ctx {
     int32_t *d_col = nullptr;
     // TILED layout
     emsar::TiledLayout TL;       // host copy keeps slot_row / single_* / left_row (index arrays freed after upload)
-    emsar::ChunkDesc *d_chunks = nullptr; emsar::GroupDesc *d_groups = nullptr; emsar::SliceDesc *d_slices = nullptr;
+    Tile *d_tiles = nullptr;
     uint32_t *d_fwd = nullptr, *d_bwd = nullptr;
     uint32_t *d_coo = nullptr;
-    int32_t *d_far = nullptr;    // explicit dictionary far lists
-    int32_t *d_far_blk = nullptr; double *d_far_w = nullptr; uint32_t *d_far_ptr = nullptr, *d_far_dst = nullptr;   // exported far entries
-    int64_t n_far_exported = 0;
-    int64_t n_pairs = 0; int32_t *d_pair_tid = nullptr; uint32_t *d_pair_dst = nullptr; int32_t *d_pair_wgt = nullptr; double *d_pair_val = nullptr;
-    int n_wg_slots = 1024;       // workgroups of the pass kernel the device holds at once (4 per CU)
-    unsigned long long *d_stamps = nullptr;   // non-null only inside emsar_hip_debug_chunk_times
+    int32_t *d_far = nullptr;
     uint64_t *d_left_ptr = nullptr; int32_t *d_left_col = nullptr; int32_t *d_left_wgt = nullptr; double *d_left_val = nullptr;
-    int64_t n_left = 0, n_chunks = 0, n_slots = 0;
+    int64_t n_left = 0, n_tiles = 0, n_slots = 0;
     double *d_u = nullptr;       // folded single-tid rows: per-transcript weight sum
     // sample
     bool weighted = false;
@@ -87,13 +82,15 @@ struct emsar_hip_ctx {
     Scal *d_scal = nullptr;
     Scal *h_scal = nullptr;      // pinned
     int64_t bytes_formula = 0, bytes_stored = 0;
-    int64_t tl_fwd_slots = 0, tl_n_fslices = 0, tl_far_entries = 0;
+    int64_t tl_fwd_slots = 0, tl_n_fslices = 0;
     double count_floor = 0.0;    // stopping-rule floor in reads for the current solve (emsar_em_params.count_floor)
     double zero_cut = 0.0;       // emsar_em_params.zero_cut of the current solve
     bool use_graph = true;       // replay check_every cycles of the streaming solve from one hipGraph (EMSAR_HIP_GRAPH=0: launch each kernel)
     int64_t graph_launches = 0;  // of the last solve (debug: EMSAR_HIP_DEBUG)
     int update_grid = 256;       // workgroups of k_update (EMSAR_HIP_UPDATE_GRID)
     int sq_grid = 256;           // workgroups of the SQUAREM vector kernels (EMSAR_HIP_SQ_GRID)
+    int tiled_multi = 1;         // EMSAR_HIP_TILED_MULTI 1: two tiles per workgroup (k_pass_tiled_multi) above kPairMinTiles tiles, else one
+                                 // (k_pass_tiled); 2: always two; 0: always one
     const uint8_t *delta_mask = nullptr;   // d_kind while the streaming solve runs next to resident sets
     // set-resident solver (sets.hpp): host copy of the CSR and of the sample's row weights, built lazily by solve
     std::vector<uint64_t> h_row_ptr;
@@ -149,15 +146,11 @@ void free_structure(emsar_hip_ctx *ctx) {
     dfree(ctx->d_row_ptr); dfree(ctx->d_col);
     ctx->d_row_ptr = nullptr; ctx->d_col = nullptr;
     dfree(ctx->d_wgt); dfree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
-    dfree(ctx->d_chunks); dfree(ctx->d_groups); dfree(ctx->d_slices); dfree(ctx->d_fwd); dfree(ctx->d_bwd); dfree(ctx->d_coo); dfree(ctx->d_far);
-    dfree(ctx->d_far_blk); dfree(ctx->d_far_w); dfree(ctx->d_far_ptr); dfree(ctx->d_far_dst);
-    ctx->d_far_blk = nullptr; ctx->d_far_w = nullptr; ctx->d_far_ptr = ctx->d_far_dst = nullptr; ctx->n_far_exported = 0;
-    dfree(ctx->d_pair_tid); dfree(ctx->d_pair_dst); dfree(ctx->d_pair_wgt); dfree(ctx->d_pair_val);
-    ctx->d_pair_tid = nullptr; ctx->d_pair_dst = nullptr; ctx->d_pair_wgt = nullptr; ctx->d_pair_val = nullptr; ctx->n_pairs = 0;
+    dfree(ctx->d_tiles); dfree(ctx->d_fwd); dfree(ctx->d_bwd); dfree(ctx->d_coo); dfree(ctx->d_far);
     dfree(ctx->d_left_ptr); dfree(ctx->d_left_col); dfree(ctx->d_left_wgt); dfree(ctx->d_left_val); dfree(ctx->d_u);
-    ctx->d_chunks = nullptr; ctx->d_groups = nullptr; ctx->d_slices = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_coo = nullptr; ctx->d_far = nullptr;
+    ctx->d_tiles = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_coo = nullptr; ctx->d_far = nullptr;
     ctx->d_left_ptr = nullptr; ctx->d_left_col = nullptr; ctx->d_left_wgt = nullptr; ctx->d_left_val = nullptr; ctx->d_u = nullptr;
-    ctx->TL = emsar::TiledLayout(); ctx->n_left = ctx->n_chunks = ctx->n_slots = 0;
+    ctx->TL = emsar::TiledLayout(); ctx->n_left = ctx->n_tiles = ctx->n_slots = 0;
     dfree(ctx->d_den); dfree(ctx->d_acc); ctx->d_den = nullptr; ctx->d_acc = nullptr;
     for (auto &p : ctx->d_th) { dfree(p); p = nullptr; }
     for (auto &p : ctx->d_tmp) { dfree(p); p = nullptr; }
@@ -165,46 +158,34 @@ void free_structure(emsar_hip_ctx *ctx) {
     ctx->have_structure = ctx->have_sample = false;
 }
 
-// the exported far entries of the TILED layout as the update kernels see them (null: none)
-inline FarList far_list(const emsar_hip_ctx *ctx) {
-    if (ctx->layout != EMSAR_LAYOUT_TILED || ctx->n_far_exported == 0) return FarList{nullptr, nullptr};
-    return FarList{ctx->d_far_ptr, ctx->d_far_w};
-}
-
 // one pass of the chosen layout.  mode: MODE_EM / MODE_EM_LL / MODE_SCATTER
 int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, double *ll_out, bool rows_only = false /* the folded rows' likelihood terms are added by the caller */) {
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
         const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
-        const bool with_pairs = ctx->n_pairs > 0;
-        if (with_pairs) {
-            HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-            HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
-        }
-        if (ctx->n_chunks > 0) {
-            dim3 grid((unsigned)ctx->n_chunks), block(kTiledThreads);
-            const TiledArgs A{ctx->d_chunks, ctx->d_groups, ctx->d_slices, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_far_blk, ctx->d_far_dst,
-                              ctx->d_far_w, ctx->d_wgt, ctx->d_rowval, ctx->d_stamps};
-#define LAUNCH_T(WT, MD) hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, A, theta, acc, ll_out)
+        if (ctx->n_tiles > 0) {
+            dim3 grid((unsigned)ctx->n_tiles), block(kTiledThreads);
+#define LAUNCH_T(WT, MD)                                                                                          \
+    hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, ctx->d_tiles, ctx->d_fwd, ctx->d_bwd,   \
+                       ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out)
+#define LAUNCH_PN(WT, MD, NN)                                                                                     \
+    hipLaunchKernelGGL((k_pass_tiled_multi<WT, MD, NN>), dim3((unsigned)((ctx->n_tiles + NN - 1) / NN)), block, lds, ctx->stream, ctx->d_tiles,  \
+                       (int)ctx->n_tiles, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, theta, acc, ll_out)
+#define LAUNCH_P(WT, MD) LAUNCH_PN(WT, MD, 2)
             if (mode == MODE_SCATTER) LAUNCH_T(false, MODE_SCATTER);
+            else if (!ctx->weighted && (ctx->tiled_multi >= 2 || (ctx->tiled_multi == 1 && ctx->n_tiles > kPairMinTiles))) {
+                // two tiles per workgroup, software-pipelined: +3 % on config 3.  Unweighted rows only: with the row
+                // weights in registers as well the two-tile body does not fit 128 VGPRs (0.218 vs 0.179 ms measured).
+                // Only when the tiles outnumber the chip's workgroup slots: below that a pass is one workgroup's latency, and
+                // a pair takes twice as long as a tile (40 k reads: 47 -> 26 us per pass with one tile per workgroup)
+                if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM);
+            }
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
             else { if (mode == MODE_EM_LL) LAUNCH_T(false, MODE_EM_LL); else LAUNCH_T(false, MODE_EM); }
+#undef LAUNCH_P
+#undef LAUNCH_PN
 #undef LAUNCH_T
         }
-        // the pairs on a side stream, next to the pass kernel (both only read theta; they write disjoint places of far_w).  Submitted AFTER
-        // the pass kernel: its workgroups own every VGPR of the CUs they sit on, so the pairs run where chunks have finished (the tail)
-        // -- launched first, the pairs' resident workgroups kept a quarter of the chunks off the CUs for 125 us.
-        if (with_pairs) {
-            const dim3 pg((unsigned)std::min<int64_t>((ctx->n_pairs + 255) / 256, 2048)), pb(256);
-#define LAUNCH_P(WT, MD) hipLaunchKernelGGL((k_pass_pairs<WT, MD>), pg, pb, 0, ctx->side[0], ctx->n_pairs, ctx->d_pair_tid, ctx->d_pair_dst, \
-                                           ctx->d_pair_wgt, ctx->d_pair_val, theta, ctx->d_far_w, ll_out)
-            if (mode == MODE_SCATTER) LAUNCH_P(false, MODE_SCATTER);
-            else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_P(true, MODE_EM_LL); else LAUNCH_P(true, MODE_EM); }
-            else { if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM); }
-#undef LAUNCH_P
-            HIPCHK(hipEventRecord(ctx->ev_join[0], ctx->side[0]));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
-        }
-        if (ctx->n_left > 0) {   // rows too long for a slice: generic CSR kernel on the leftover
+        if (ctx->n_left > 0) {   // rows too long for a tile: generic CSR kernel on the leftover
             dim3 grid((unsigned)std::min<int64_t>((ctx->n_left + 255) / 256, 8192)), block(256);
 #define LAUNCH_L(WT, MD)                                                                                          \
     hipLaunchKernelGGL((k_pass_csr<uint64_t, WT, MD>), grid, block, 0, ctx->stream, ctx->n_left, ctx->d_left_ptr,     \
@@ -214,8 +195,6 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
             else { if (mode == MODE_EM_LL) LAUNCH_L(false, MODE_EM_LL); else LAUNCH_L(false, MODE_EM); }
 #undef LAUNCH_L
         }
-        if (mode == MODE_SCATTER && ctx->n_far_exported > 0)      // the scattered value of the rows with an exported entry, to that entry's transcript
-            hipLaunchKernelGGL(k_far_add, dim3(grid_for(ctx->n_tx, 256)), dim3(256), 0, ctx->stream, ctx->n_tx, far_list(ctx), acc);
         if (mode == MODE_EM_LL && !rows_only)
             hipLaunchKernelGGL(k_single_ll, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx,
                                ctx->d_u, theta, ll_out);
@@ -242,12 +221,9 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
 int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_ll, int ll_slot, double abs_floor, int to_delta1 = 0) {
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot].v);
     if (rc) return rc;
-    // with exported far entries every workgroup iteration is a chain of dependent trips to memory (run bounds -> far_w -> LDS):
-    // one iteration per workgroup, all of them in flight together
-    const int ug = far_list(ctx).ptr ? grid_for(ctx->n_tx, 256) : std::min(grid_for(ctx->n_tx, 256), ctx->update_grid);
-    hipLaunchKernelGGL(k_update, dim3(ug), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
+    hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), ctx->update_grid)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
                        ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->zero_cut, ctx->d_scal,
-                       ctx->delta_mask, to_delta1, far_list(ctx));
+                       ctx->delta_mask, to_delta1);
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
 }
@@ -269,13 +245,12 @@ int enqueue_cycles(emsar_hip_ctx *ctx, const emsar_em_params &p, double abs_step
         // the stopping rule is measured on the first (plain) step of the cycle only (delta1_bits)
         const double *u = ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr;
         const dim3 gv((unsigned)std::min(g, ctx->sq_grid)), bv(256);
-        const dim3 gf((unsigned)(far_list(ctx).ptr ? g : std::min(g, ctx->sq_grid)));      // kernels that add the exported far sums
         if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor, 1))) return rc;
         if ((rc = launch_pass(ctx, MODE_EM_LL, th[1], ctx->d_acc, &ctx->d_scal->ll[1].v, true))) return rc;
-        hipLaunchKernelGGL(k_update_p2, gf, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal, far_list(ctx));
+        hipLaunchKernelGGL(k_update_p2, gv, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal);
         hipLaunchKernelGGL(k_sq_extrap_ll, gv, bv, 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, u, th[3], ctx->d_scal);
         if ((rc = launch_pass(ctx, MODE_EM_LL, th[3], ctx->d_acc, &ctx->d_scal->ll[2].v, true))) return rc;
-        hipLaunchKernelGGL(k_update_p3, gf, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal, far_list(ctx));
+        hipLaunchKernelGGL(k_update_p3, gv, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal);
         HIPCHK(hipGetLastError());
     }
     return EMSAR_HIP_OK;
@@ -304,14 +279,6 @@ int scatter_rows(emsar_hip_ctx *ctx, const double *val_host, double *d_out) {
                 else slot[(size_t)i] = val_host[r];
             }
             for (int64_t i = 0; i < ctx->n_left; i++) left[(size_t)i] = val_host[L.left_row[(size_t)i]];
-            std::vector<double> pairv((size_t)std::max<int64_t>(ctx->n_pairs, 1), 0.0);
-            for (int64_t i = 0; i < ctx->n_pairs; i++) {
-                const int64_t r = L.pair_row[(size_t)i];
-                if (L.merged) { double v = 0; for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) v += val_host[L.mem_row[(size_t)q]]; pairv[(size_t)i] = v; }
-                else pairv[(size_t)i] = val_host[r];
-            }
-            if (!ctx->d_pair_val) HIPCHK(hipMalloc(&ctx->d_pair_val, pairv.size() * sizeof(double)));
-            HIPCHK(hipMemcpyAsync(ctx->d_pair_val, pairv.data(), pairv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
             for (size_t i = 0; i < L.single_row.size(); i++) base[(size_t)L.single_tid[i]] += val_host[L.single_row[i]];
             if (!ctx->d_rowval) HIPCHK(hipMalloc(&ctx->d_rowval, slot.size() * sizeof(double)));
             if (!ctx->d_left_val) HIPCHK(hipMalloc(&ctx->d_left_val, left.size() * sizeof(double)));
@@ -518,67 +485,37 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
     try {
         if (layout == EMSAR_LAYOUT_TILED) {
             auto &L = ctx->TL;
-            {   // as many chunks as the device holds workgroups of the pass kernel: 4 per CU (LDS and registers both allow 4)
-                hipDeviceProp_t prop;
-                if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_wg_slots = 4 * prop.multiProcessorCount;
-            }
-            const int brc = emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows, ctx->n_wg_slots);
+            const int brc = emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows);
             if (brc != 0) { ctx->err = "TILED layout builder: code " + std::to_string(brc); return EMSAR_HIP_ERR_ARG; }
             if (dbg) fprintf(stderr, "upload_structure: layout built after %.0f ms\n", since(tu0));
-            ctx->n_chunks = (int64_t)L.chunks.size(); ctx->n_slots = L.n_slots(); ctx->n_left = (int64_t)L.left_row.size();
-            ctx->n_far_exported = L.n_exported;
-            ctx->n_pairs = (int64_t)L.pair_row.size();
+            ctx->n_tiles = (int64_t)L.tiles.size(); ctx->n_slots = L.n_slots(); ctx->n_left = (int64_t)L.left_row.size();
             auto up = [&](void **dp, const void *src, size_t bytes) -> hipError_t {
                 hipError_t e = hipMalloc(dp, std::max<size_t>(bytes, 16));
                 if (e == hipSuccess && bytes) e = hipMemcpy(*dp, src, bytes, hipMemcpyHostToDevice);
                 return e;
             };
-            HIPCHK(up((void **)&ctx->d_chunks, L.chunks.data(), L.chunks.size() * sizeof(emsar::ChunkDesc)));
-            HIPCHK(up((void **)&ctx->d_groups, L.groups.data(), L.groups.size() * sizeof(emsar::GroupDesc)));
-            HIPCHK(up((void **)&ctx->d_slices, L.slices.data(), L.slices.size() * sizeof(emsar::SliceDesc)));
+            HIPCHK(up((void **)&ctx->d_tiles, L.tiles.data(), L.tiles.size() * sizeof(Tile)));
             HIPCHK(up((void **)&ctx->d_fwd, L.fwd.data(), L.fwd.size() * 4));
             HIPCHK(up((void **)&ctx->d_bwd, L.bwd.data(), L.bwd.size() * 4));
             HIPCHK(up((void **)&ctx->d_coo, L.coo.data(), L.coo.size() * 4));
             HIPCHK(up((void **)&ctx->d_far, L.far_tid.data(), L.far_tid.size() * 4));
-            HIPCHK(up((void **)&ctx->d_far_blk, L.far_blk_tid.data(), L.far_blk_tid.size() * 4));
-            HIPCHK(up((void **)&ctx->d_far_ptr, L.far_ptr.data(), L.far_ptr.size() * 4));
-            {   // the layout lists the exported entries by transcript (far_ptr / far_src); the kernels want the inverse: for every far
-                // row of a slice and for both entries of a pair, its entry's place in that order
-                const size_t nb = L.far_blk_tid.size();
-                std::vector<uint32_t> blk_dst(nb, 0xFFFFFFFFu), pair_dst(L.pair_tid.size(), 0xFFFFFFFFu);
-                for (int32_t t = 0; t < n_tx; t++)
-                    for (uint32_t q = L.far_ptr[(size_t)t]; q < L.far_ptr[(size_t)t + 1]; q++) {
-                        const uint32_t x = L.far_src[q];
-                        if (x < nb) blk_dst[x] = q;
-                        else { const size_t i = x - nb; pair_dst[2 * i + (L.pair_tid[2 * i] == t ? 0 : 1)] = q; }
-                    }
-                HIPCHK(up((void **)&ctx->d_far_dst, blk_dst.data(), blk_dst.size() * 4));
-                HIPCHK(up((void **)&ctx->d_pair_dst, pair_dst.data(), pair_dst.size() * 4));
-            }
-            HIPCHK(up((void **)&ctx->d_pair_tid, L.pair_tid.data(), L.pair_tid.size() * 4));
-            const size_t n_far_w = std::max<size_t>((size_t)L.n_exported, 2);
-            HIPCHK(hipMalloc(&ctx->d_far_w, n_far_w * 8));
-            HIPCHK(hipMemset(ctx->d_far_w, 0, n_far_w * 8));
             HIPCHK(up((void **)&ctx->d_left_ptr, L.left_ptr.data(), L.left_ptr.size() * 8));
             HIPCHK(up((void **)&ctx->d_left_col, L.left_col.data(), L.left_col.size() * 4));
             HIPCHK(hipMalloc(&ctx->d_u, T * 8));
             HIPCHK(hipMemset(ctx->d_u, 0, T * 8));
-            // what one pass streams: both indices, the COO and far lists, the descriptors, the far blocks (tids read, weights
-            // written by the pass and read back by the update kernel through far_pos)
             ctx->bytes_stored = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 + (int64_t)L.far_tid.size() * 4 +
-                                (int64_t)L.slices.size() * 32 + (int64_t)L.groups.size() * 32 + (int64_t)L.chunks.size() * 8 +
-                                (int64_t)L.far_blk_tid.size() * (4 + 4) + L.n_exported * (8 + 8) + (L.n_exported ? (int64_t)L.far_ptr.size() * 4 : 0) +
-                                (int64_t)L.pair_tid.size() * (4 + 4) +
-                                (int64_t)L.left_col.size() * 4 + (int64_t)L.left_ptr.size() * 8;
-            ctx->tl_fwd_slots = L.padded_slots; ctx->tl_n_fslices = (int64_t)L.slices.size();
-            ctx->tl_far_entries = L.far_entries + L.n_exported;
+                                (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4 + (int64_t)L.left_ptr.size() * 8;
+            ctx->tl_fwd_slots = L.padded_slots; ctx->tl_n_fslices = L.n_fslices;
             emsar::u32_vec().swap(L.fwd); emsar::u32_vec().swap(L.bwd); std::vector<uint32_t>().swap(L.coo);
-            std::vector<int32_t>().swap(L.left_col); std::vector<int32_t>().swap(L.far_blk_tid);
-            std::vector<uint32_t>().swap(L.far_src); std::vector<uint32_t>().swap(L.far_ptr);
+            std::vector<int32_t>().swap(L.left_col);
             const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
 #define SETLDS_T(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             SETLDS_T(false, MODE_EM); SETLDS_T(false, MODE_EM_LL); SETLDS_T(true, MODE_EM); SETLDS_T(true, MODE_EM_LL); SETLDS_T(false, MODE_SCATTER);
 #undef SETLDS_T
+#define SETLDS_P(WT, MD, NN) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_multi<WT, MD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+            SETLDS_P(false, MODE_EM, 2); SETLDS_P(false, MODE_EM_LL, 2);
+#undef SETLDS_P
+            { const char *pe = getenv("EMSAR_HIP_TILED_MULTI"); ctx->tiled_multi = pe ? atoi(pe) : 1; }
             { const char *pe = getenv("EMSAR_HIP_UPDATE_GRID"); if (pe && atoi(pe) >= 1) ctx->update_grid = atoi(pe); }
             { const char *pe = getenv("EMSAR_HIP_SQ_GRID"); if (pe && atoi(pe) >= 1) ctx->sq_grid = atoi(pe); }
         } else {
@@ -682,27 +619,6 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
                 wl[(size_t)i] = x;
                 if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[r]);
             }
-            std::vector<int32_t> wp((size_t)std::max<int64_t>(ctx->n_pairs, 1), 0);       // the pairs, like the slots
-            for (int64_t i = 0; i < ctx->n_pairs; i++) {
-                const int64_t r = L.pair_row[(size_t)i];
-                int64_t sum = 0;
-                if (L.merged) {
-                    for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) {
-                        const int64_t o = L.mem_row[(size_t)q];
-                        const int32_t x = weight_of(o);
-                        sum += x;
-                        if (x > 0 && row_E) ctx->loglik_const += (double)x * std::log(row_E[o]);
-                    }
-                } else {
-                    sum = weight_of(r);
-                    if (sum > 0 && row_E) ctx->loglik_const += (double)sum * std::log(row_E[r]);
-                }
-                if (sum > INT32_MAX) return EMSAR_HIP_ERR_ARG;
-                wp[(size_t)i] = (int32_t)sum;
-            }
-            dfree(ctx->d_pair_wgt); ctx->d_pair_wgt = nullptr;
-            HIPCHK(hipMalloc(&ctx->d_pair_wgt, wp.size() * 4));
-            HIPCHK(hipMemcpy(ctx->d_pair_wgt, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMalloc(&ctx->d_wgt, w.size() * 4));
             HIPCHK(hipMemcpy(ctx->d_wgt, w.data(), w.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMalloc(&ctx->d_left_wgt, wl.size() * 4));
@@ -995,42 +911,40 @@ int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *o) {
     o->n_rows = ctx->n_rows; o->nnz = ctx->nnz; o->n_tx = ctx->n_tx; o->device_id = ctx->device;
     o->layout = ctx->layout | ((ctx->layout == EMSAR_LAYOUT_TILED && ctx->TL.merged) ? EMSAR_LAYOUT_FLAG_MERGE_ROWS : 0);
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
-        o->n_chunks = ctx->n_chunks; o->n_slices = ctx->tl_n_fslices; o->padded_entries = ctx->tl_fwd_slots;
-        o->far_entries = ctx->tl_far_entries; o->window = emsar::kTileDict;
-        o->n_groups = (int64_t)ctx->TL.groups.size(); o->exported_entries = ctx->n_far_exported;
+        o->n_chunks = ctx->n_tiles; o->n_slices = ctx->tl_n_fslices; o->padded_entries = ctx->tl_fwd_slots;
+        o->far_entries = ctx->TL.far_entries; o->window = emsar::kTileDict;
     }
     o->bytes_per_pass = ctx->bytes_formula;
     o->stored_bytes_per_pass = stored_bytes(ctx);
     return EMSAR_HIP_OK;
 }
 
-// Diagnostic only (not declared in the public header): one stamped pass of the TILED kernel on the current theta (theta is
-// left untouched, acc is cleared again).  out[8 * (4 * chunk + wave) + i]: i = 0 start, 1 end of the wave on the 100 MHz clock,
-// 2 shader cycles spent inside slices, 3 slices processed, 4..7 cycles per phase (loads issued, E-step, weights + next slice's
-// loads, M-step); then, from out[32 * n_chunks], five values per slice: shader cycles, k, m, coo_n, nf | chunk << 8.
-// n_out >= 32 * n_chunks + 5 * n_slices.
-int emsar_hip_debug_chunk_times(emsar_hip_ctx *ctx, unsigned long long *out, int64_t n_out) {
-    if (!ctx || !out || ctx->layout != EMSAR_LAYOUT_TILED || !ctx->have_sample || ctx->n_chunks == 0) return EMSAR_HIP_ERR_STATE;
-    const size_t nw = (size_t)ctx->n_chunks * emsar::kTileWaves * 8, ns = ctx->TL.slices.size(), n = nw + ns;
-    if (n_out < (int64_t)(nw + 5 * ns)) return EMSAR_HIP_ERR_ARG;
+// Diagnostic only (not declared in the public header): one stamped pass of the TILED kernel on the current theta.
+// out[0..6] = mean cycles per wave spent in: loads issued + dictionary, barrier, E-step, barrier, M-step, barrier, flush;
+// out[7] = tiles.  The result vector theta is left untouched (acc is cleared again).
+int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
+    if (!ctx || !out || ctx->layout != EMSAR_LAYOUT_TILED || !ctx->have_sample || ctx->weighted || ctx->n_tiles == 0) return EMSAR_HIP_ERR_STATE;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMalloc(&ctx->d_stamps, n * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(ctx->d_stamps, 0, n * sizeof(unsigned long long), ctx->stream);
-    int rc = EMSAR_HIP_OK;
-    std::vector<unsigned long long> tmp(n);
-    if (e == hipSuccess) rc = launch_pass(ctx, MODE_EM, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].v);
-    if (e == hipSuccess && rc == EMSAR_HIP_OK) e = hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream);
-    if (e == hipSuccess && rc == EMSAR_HIP_OK) e = hipMemcpyAsync(tmp.data(), ctx->d_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && rc == EMSAR_HIP_OK) e = hipStreamSynchronize(ctx->stream);
-    dfree(ctx->d_stamps); ctx->d_stamps = nullptr;
-    if (rc) return rc;
-    HIPCHK(e);
-    for (size_t i = 0; i < nw; i++) out[i] = tmp[i];
-    for (size_t i = 0; i < ns; i++) {
-        const emsar::SliceDesc &D = ctx->TL.slices[i];
-        unsigned long long *o = out + nw + 5 * i;
-        o[0] = tmp[nw + i] & ((1ull << 40) - 1); o[1] = D.k; o[2] = D.m; o[3] = D.coo_n; o[4] = D.nf | ((tmp[nw + i] >> 40) << 8);      // nf, and the chunk that ran the slice
+    unsigned long long *d = nullptr;
+    const size_t nw = (size_t)ctx->n_tiles * (kTiledThreads / 64), bytes = nw * 8 * sizeof(unsigned long long);
+    HIPCHK(hipMalloc(&d, bytes));
+    HIPCHK(hipMemsetAsync(d, 0, bytes, ctx->stream));
+    const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
+    HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<false, MODE_EM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_pass_tiled<false, MODE_EM, true>), dim3((unsigned)ctx->n_tiles), dim3(kTiledThreads), lds, ctx->stream, ctx->d_tiles,
+                       ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].v, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
+    std::vector<unsigned long long> h(nw * 8);
+    HIPCHK(hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dfree(d);
+    for (int i = 0; i < 7; i++) {
+        double sum = 0;
+        for (size_t w = 0; w < nw; w++) sum += (double)h[w * 8 + (size_t)i];
+        out[i] = sum / (double)nw;   // mean cycles per wave
     }
+    out[7] = (double)ctx->n_tiles;
     return EMSAR_HIP_OK;
 }
 
@@ -1045,13 +959,11 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
             memset(info_out, 0, sizeof(*info_out));
             info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx;
             info_out->layout = EMSAR_LAYOUT_TILED | (L.merged ? EMSAR_LAYOUT_FLAG_MERGE_ROWS : 0);
-            info_out->n_chunks = (int64_t)L.chunks.size();
-            info_out->n_slices = (int64_t)L.slices.size();
-            info_out->n_groups = (int64_t)L.groups.size(); info_out->exported_entries = L.n_exported;
-            info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries + L.n_exported; info_out->window = emsar::kTileDict;
+            info_out->n_chunks = (int64_t)L.tiles.size();
+            info_out->n_slices = L.n_fslices;
+            info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries; info_out->window = emsar::kTileDict;
             info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 +
-                                              (int64_t)L.far_tid.size() * 4 + (int64_t)L.slices.size() * 32 + (int64_t)L.groups.size() * 32 +
-                                              (int64_t)L.far_blk_tid.size() * 12 + L.n_exported * 12 + (int64_t)L.pair_tid.size() * 4 + (int64_t)L.left_col.size() * 4;
+                                              (int64_t)L.far_tid.size() * 4 + (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4;
             info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
         }
         return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;

@@ -3,7 +3,7 @@
 // included by emsar_hip.hip only (one translation unit: the kernels live in its anonymous namespace)
 
 namespace {
-
+using emsar::Tile;
 
 // ------------------------------------------------------------------------------------------------
 // device scalars of one solve (lives in HBM, polled by the host every check_every cycles)

@@ -12,89 +12,18 @@ __global__ void k_fill_start(int n, const double *__restrict__ den, double *__re
     if (t < n) theta[t] = den[t] > 0.0 ? 1.0 : 0.0;  // uniform interior start; tids outside F are defined 0
 }
 
-// Exported far entries of the TILED layout (layout_tiled.hpp): the pass kernel stores the weight w_r of every row with an
-// exported entry (and of every pair, twice) at that entry's place in far_w, which lists the exported entries in transcript
-// order; the M-step sum of transcript t is acc_t + the contiguous run far_w[ptr[t] .. ptr[t+1]) -- summed here in fixed order
-// instead of one scattered atomic per entry in the pass kernel.  ptr == nullptr: no such entries.
-struct FarList { const uint32_t *ptr; const double *w; };
-__device__ __forceinline__ double far_sum(const FarList &F, int t) {
-    double s = 0.0;
-    if (F.ptr) for (uint32_t q = F.ptr[t], e = F.ptr[t + 1]; q < e; q++) s += F.w[q];      // a contiguous run, in transcript order
-    return s;
-}
-// The same sums for the 256 consecutive transcripts [t_base, t_base + 256) of one workgroup iteration: their runs are one
-// contiguous stretch of far_w, which the workgroup copies into LDS with coalesced loads (one round trip to memory for the whole
-// stretch -- far_w was written by the pass kernel, possibly on another XCD, so every line is a miss, and a thread that chased its
-// own run entry by entry took 0.5 ms) before the runs are added up.
-// A run of up to kFarSerial entries is summed by its own thread, in ascending order.  Longer runs (a transcript that is the far
-// hit of thousands of rows: summed by one thread, 2000 entries took 80 us) are summed by a wavefront each: lane i takes entries
-// i, i + 64, ... and the 64 partial sums go through a fixed butterfly -- another order of additions than far_sum's, but the
-// same one in every run of the program.  A stretch longer than the stage goes through in
-// pieces.  Every thread of the workgroup must call it (barriers inside), also those with t >= n.
-constexpr int kFarStage = 2048;
-constexpr uint32_t kFarSerial = 48;
-struct FarLds { double stage[kFarStage]; double tree[256]; uint32_t long_lo[256], long_hi[256]; int n_long; };
-__device__ __forceinline__ double far_sum_block(const FarList &F, int t_base, int n, int t, FarLds &L) {
-    if (!F.ptr) return 0.0;
-    const int t_end = t_base + 256 < n ? t_base + 256 : n;
-    const uint32_t q0 = F.ptr[t_base], q1 = F.ptr[t_end];          // workgroup-uniform
-    uint32_t a = 0, b = 0;
-    if (t < n) { a = F.ptr[t]; b = F.ptr[t + 1]; }
-    double s = 0.0;
-    for (uint32_t base = q0; base < q1; base += kFarStage) {
-        const uint32_t cnt = q1 - base < (uint32_t)kFarStage ? q1 - base : (uint32_t)kFarStage;
-        __syncthreads();                                            // the previous piece has been consumed
-        if (threadIdx.x == 0) L.n_long = 0;
-        double v[kFarStage / 256];                                  // all loads of the piece in flight together
-#pragma unroll
-        for (int j = 0; j < kFarStage / 256; j++) { const uint32_t i = threadIdx.x + 256u * (uint32_t)j; v[j] = i < cnt ? F.w[base + i] : 0.0; }
-#pragma unroll
-        for (int j = 0; j < kFarStage / 256; j++) { const uint32_t i = threadIdx.x + 256u * (uint32_t)j; if (i < cnt) L.stage[i] = v[j]; }
-        __syncthreads();
-        const uint32_t lo = a > base ? a : base, hi = b < base + cnt ? b : base + cnt;
-        int my_long = -1;
-        if (lo < hi) {
-            if (hi - lo <= kFarSerial) { for (uint32_t q = lo; q < hi; q++) s += L.stage[q - base]; }
-            else { my_long = atomicAdd(&L.n_long, 1); L.long_lo[my_long] = lo - base; L.long_hi[my_long] = hi - base; }
-        }
-        __syncthreads();
-        const int n_long = L.n_long;                                // workgroup-uniform
-        // long runs: one wavefront each (lane i takes entries i, i + 64, ...; the 64 partial sums go through a fixed butterfly),
-        // four at a time; the totals are handed to the owners through LDS
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int k = wave; k < n_long; k += 4) {
-            double p = 0.0;
-            for (uint32_t q = L.long_lo[k] + (uint32_t)lane; q < L.long_hi[k]; q += 64) p += L.stage[q];
-            for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-            if (lane == 0) L.tree[k] = p;
-        }
-        __syncthreads();
-        if (my_long >= 0) s += L.tree[my_long];
-    }
-    return s;
-}
-// out_t += sum of the exported entries (scatter passes: den, iEUMA)
-__global__ __launch_bounds__(256) void k_far_add(int n, const FarList F, double *__restrict__ out) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < n) { const double s = far_sum(F, t); if (s != 0.0) out[t] += s; }
-}
-
 // theta_out = theta_in * acc / den ; acc <- 0 ; scal.delta = max |dtheta| / (theta_out + floor)
 // grid-stride, one atomicMax per workgroup (hundreds of same-address atomics cost ~12 ns each)
 __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict__ th_in, double *__restrict__ acc,
                                                 const double *__restrict__ den, const double *__restrict__ u /* folded single-tid rows, may be null */,
                                                 double *__restrict__ th_out, double abs_floor, double count_floor, double zero_cut, Scal *scal,
                                                 const uint8_t *__restrict__ kind /* non-null: only KIND_STREAMED transcripts enter the stopping rule */,
-                                                int to_delta1 /* the first (plain) step of a SQUAREM cycle: the cycle's stopping rule */, const FarList F) {
+                                                int to_delta1 /* the first (plain) step of a SQUAREM cycle: the cycle's stopping rule */) {
     __shared__ double red[4];
-    __shared__ FarLds stage;
     double d = 0.0;
     const double abs_step = scal->abs_step_cur;      // written by k_cycle_begin, nobody writes it during a pass
-    for (int t_base = blockIdx.x * 256; t_base < n; t_base += gridDim.x * 256) {
-        const int t = t_base + threadIdx.x;
-        const double fs = far_sum_block(F, t_base, n, t, stage);
-        if (t >= n) continue;
-        double a = acc[t] + fs, dn = den[t], x = th_in[t];
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+        double a = acc[t], dn = den[t], x = th_in[t];
         // a row {t} contributes R/theta_t to acc_t, i.e. R to theta_t*acc_t: added analytically (TILED layout)
         double y = dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
         th_out[t] = y;
@@ -146,17 +75,12 @@ __device__ __forceinline__ double em_new_theta(double x, double a, double dn, co
     return dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
 }
 __global__ __launch_bounds__(256) void k_update_p2(int n, const double *__restrict__ th0, const double *__restrict__ th1, double *__restrict__ acc,
-                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th2, Scal *scal,
-                                                   const FarList F) {
+                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th2, Scal *scal) {
     __shared__ double red[4];
-    __shared__ FarLds stage;
     double r2 = 0, v2 = 0, p1 = 0, l1 = 0;
-    for (int t_base = blockIdx.x * 256; t_base < n; t_base += gridDim.x * 256) {
-        const int t = t_base + threadIdx.x;
-        const double fs = far_sum_block(F, t_base, n, t, stage);
-        if (t >= n) continue;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
         const double x = th1[t], dn = den[t];
-        const double y = em_new_theta(x, acc[t] + fs, dn, u, t);
+        const double y = em_new_theta(x, acc[t], dn, u, t);
         th2[t] = y;
         acc[t] = 0.0;
         const double r = x - th0[t], v = (y - x) - r;
@@ -200,17 +124,12 @@ __global__ __launch_bounds__(256) void k_sq_extrap_ll(int n, const double *__res
     }
 }
 __global__ __launch_bounds__(256) void k_update_p3(int n, const double *__restrict__ thx, const double *__restrict__ th2, double *__restrict__ acc,
-                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th0, Scal *scal,
-                                                   const FarList F) {
+                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th0, Scal *scal) {
     const double s = scal->s_used;
     const bool extrap = s > 1.0;
     const bool ok = !extrap || (scal->ll[2].v - scal->penx.v >= scal->ll[1].v - scal->pen1.v);
-    __shared__ FarLds stage;
-    for (int t_base = blockIdx.x * 256; t_base < n; t_base += gridDim.x * 256) {
-        const int t = t_base + threadIdx.x;
-        const double fs = far_sum_block(F, t_base, n, t, stage);
-        if (t >= n) continue;
-        const double y = em_new_theta(thx[t], acc[t] + fs, den[t], u, t);
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+        const double y = em_new_theta(thx[t], acc[t], den[t], u, t);
         acc[t] = 0.0;
         th0[t] = ok ? y : th2[t];
     }

@@ -43,13 +43,10 @@ typedef enum {
     EMSAR_LAYOUT_AUTO = 0,   /* TILED when it applies, else CSR */
     EMSAR_LAYOUT_CSR = 1,    /* rows as given; lane-per-row walk, FP64 atomics straight to HBM/L2 */
     /* 2 was the WINDOWED layout of round 1 (4x slower than TILED, removed) */
-    EMSAR_LAYOUT_TILED = 3    /* rows sorted by (block of their median tid, length, median tid) and cut into slices of <= 768 rows,
-                                 one wavefront each: 10-bit operands (three to a dword), forward index for the E-step and a
-                                 per-slice transposed index for the M-step (no atomics in the inner loops); consecutive slices
-                                 share a dictionary of <= 959 transcripts in LDS (a group), a workgroup owns a chunk of equal
-                                 work; entries far from their row's median are exported to per-slice far blocks and summed by
-                                 the update kernel; single-tid rows folded into a per-transcript count; rows longer than 768
-                                 tids go to a small CSR of their own */
+    EMSAR_LAYOUT_TILED = 3    /* tiles of <= 4 slices x 768 rows with a tile-local dictionary of <= 959 transcripts in LDS: 10-bit
+                                 operands (three to a dword), forward index for the E-step and a per-slice transposed index for
+                                 the M-step (no atomics in the inner loops); single-tid rows folded into a per-transcript count;
+                                 rows longer than 768 tids go to a small CSR of their own */
 } emsar_hip_layout;
 
 /* OR-ed into the layout argument of emsar_hip_upload_structure (TILED only): store rows with the same tid multiset
@@ -186,21 +183,19 @@ typedef struct {
     int64_t n_rows, nnz;
     int32_t n_tx;
     int32_t layout;            /* layout in use (flags included) */
-    int64_t n_chunks;          /* TILED: chunks (one workgroup each) */
+    int64_t n_chunks;          /* TILED: tiles (one workgroup each, or one per pair of tiles) */
     int64_t n_slices;          /* TILED: 768-row slices (one wavefront at a time) */
     int64_t padded_entries;    /* stored forward slots incl. padding */
-    int64_t far_entries;       /* entries outside their group's contiguous tid range (exported ones included) */
+    int64_t far_entries;       /* entries outside their tile's contiguous tid range */
     int32_t window;            /* transcripts per dictionary */
     int32_t device_id;
     int64_t bytes_per_pass;        /* SURVEY.md 8d formula */
     int64_t stored_bytes_per_pass; /* what the layout streams */
-    int64_t n_groups;          /* TILED: groups of slices that share a dictionary */
-    int64_t exported_entries;  /* TILED: far entries served through the far blocks instead of a dictionary slot */
 } emsar_hip_info;
 int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *out);
 
 /* Host-only diagnostic (no HIP call, works without a GPU): build the TILED layout for a CSR (forward index, transposed index,
- * dictionaries, far blocks, folded and leftover rows), check every descriptor against the arrays it indexes, decode the layout
+ * dictionaries, folded and leftover rows), check every descriptor against the arrays it indexes, decode the layout
  * again and check that it stores exactly the input rows. */
 int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                                      int merge_rows, emsar_hip_info *info_out);

@@ -36,7 +36,7 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(H.EmParams) == 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 4 + 4
     assert C.sizeof(H.EmStats) == 4 + 4 + 8 * 4 + 8 * 2 + 4 * 4 + 8 * 3
     assert C.sizeof(H.SetsInfo) == 8 * 13
-    assert C.sizeof(H.Info) == 8 * 2 + 4 * 2 + 8 * 4 + 4 * 2 + 8 * 4
+    assert C.sizeof(H.Info) == 8 * 2 + 4 * 2 + 8 * 4 + 4 * 2 + 8 * 2
 
 
 def test_strerror(lib):
@@ -67,23 +67,23 @@ def test_null_and_malformed_arguments(lib):
             emsar_amd.layout_selfcheck_tiled(4, rp, np.array(bad, dtype=np.int32))
 
 
-@pytest.mark.parametrize("chunks,export", [(None, "1"), ("7", "1"), ("64", "0")])
-def test_layout_roundtrip_synthetic(lib, chunks, export, monkeypatch):
+@pytest.mark.parametrize("block,frag", [(None, None), ("128", None), (None, "3072")])
+def test_layout_roundtrip_synthetic(lib, block, frag, monkeypatch):
     """The TILED builder on a matrix with cross-family reads: descriptors inside their arrays, decoded rows = input rows,
-    for the default chunk count, a handful of chunks, and with the far-entry export switched off."""
-    if chunks:
-        monkeypatch.setenv("EMSAR_HIP_CHUNKS", chunks)
-    monkeypatch.setenv("EMSAR_HIP_FAR_EXPORT", export)
+    for the default sort block, a small one, and with the rows cut into many independently tiled fragments."""
+    if block:
+        monkeypatch.setenv("EMSAR_HIP_TILE_BLOCK", block)
+    if frag:
+        monkeypatch.setenv("EMSAR_HIP_FRAG_ROWS", frag)
+        monkeypatch.setenv("EMSAR_HOST_THREADS", "3")
     m = synth.make_matrix(n_tx=6000, n_reads=40000, law="human", xfam=0.05, seed=9)
     info = emsar_amd.layout_selfcheck_tiled(m["n_tx"], m["row_ptr"], m["col_idx"])
     nnz = len(m["col_idx"])
     assert info["nnz"] == nnz
     multi = nnz - info["folded_single_rows"]                # entries of the rows that are stored
-    assert multi - info["exported_entries"] <= info["padded_entries"]      # every stored entry has a forward slot
-    assert info["n_chunks"] == (min(int(chunks), info["n_slices"]) if chunks else min(1024, info["n_slices"]))
-    assert info["n_chunks"] <= info["n_groups"] <= info["n_slices"]
-    assert info["far_entries"] > 0                          # cross-family hits fall outside their row's window ...
-    assert (info["exported_entries"] > 0) == (export == "1")   # ... and leave through the far blocks unless that is switched off
+    assert multi <= info["padded_entries"]                  # every stored entry has a forward slot
+    assert 0 < info["n_chunks"] <= info["n_slices"] <= 4 * info["n_chunks"]
+    assert info["far_entries"] > 0                          # cross-family hits fall outside their tile's window
 
 
 def test_layout_roundtrip_edge_cases(lib):
@@ -94,10 +94,10 @@ def test_layout_roundtrip_edge_cases(lib):
     chk(5, np.array([0, 1], dtype=np.uint64), np.array([4], dtype=np.int32))
     chk(5, np.array([0, 0, 3, 3, 4], dtype=np.uint64), np.array([2, 4, 4, 0], dtype=np.int32))
     rng = np.random.default_rng(0)
-    long_row = rng.integers(0, 3000, 700).astype(np.int32)      # 700 scattered tids: far entries beyond one dictionary -> leftover CSR
+    long_row = rng.integers(0, 3000, 700).astype(np.int32)      # 700 scattered tids: one tile whose dictionary is mostly far slots
     rp = np.array([0, 700, 701], dtype=np.uint64)
     info = chk(3000, rp, np.append(long_row, 5).astype(np.int32))
-    assert info["n_slices"] == 0 and info["folded_single_rows"] == 1
+    assert info["n_slices"] == 1 and info["folded_single_rows"] == 1 and info["far_entries"] > 300
     near_row = (1000 + rng.integers(0, 300, 700)).astype(np.int32)  # 700 tids within one window: one slice of one row
     info = chk(3000, rp, np.append(near_row, 5).astype(np.int32))
     assert info["n_slices"] == 1 and info["padded_entries"] == 768 * 700

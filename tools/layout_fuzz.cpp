@@ -6,14 +6,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
-template <class T> static bool same_pod(const std::vector<T> &a, const std::vector<T> &b) {
-    return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0);
-}
 static bool same_layout(const emsar::TiledLayout &a, const emsar::TiledLayout &b) {
-    return same_pod(a.slices, b.slices) && same_pod(a.groups, b.groups) && same_pod(a.chunks, b.chunks) &&
+    return a.tiles.size() == b.tiles.size() && (a.tiles.empty() || memcmp(a.tiles.data(), b.tiles.data(), a.tiles.size() * sizeof(emsar::Tile)) == 0) &&
            a.single_row == b.single_row && a.single_tid == b.single_tid && a.slot_row == b.slot_row && a.fwd == b.fwd && a.bwd == b.bwd &&
-           a.coo == b.coo && a.far_tid == b.far_tid && a.far_blk_tid == b.far_blk_tid && a.far_ptr == b.far_ptr && a.far_src == b.far_src && a.pair_row == b.pair_row && a.pair_tid == b.pair_tid &&
-           a.left_ptr == b.left_ptr && a.left_col == b.left_col && a.left_row == b.left_row && a.mem_ptr == b.mem_ptr && a.mem_row == b.mem_row;
+           a.coo == b.coo && a.far_tid == b.far_tid && a.left_ptr == b.left_ptr && a.left_col == b.left_col && a.left_row == b.left_row &&
+           a.mem_ptr == b.mem_ptr && a.mem_row == b.mem_row;
 }
 int main(int argc, char **argv) {
     std::mt19937 rng(1);
@@ -30,8 +27,6 @@ int main(int argc, char **argv) {
             for (int j = 0; j < k; j++) ci.push_back(rng() % 10 == 0 ? (int)(rng() % n_tx) : std::min(n_tx - 1, t0 + j % 64));
             rp.push_back(ci.size());
         }
-        if (trial % 3 == 0) setenv("EMSAR_HIP_CHUNKS", trial % 2 ? "3" : "40", 1); else unsetenv("EMSAR_HIP_CHUNKS");
-        if (trial % 5 == 4) setenv("EMSAR_HIP_FAR_EXPORT", "0", 1); else unsetenv("EMSAR_HIP_FAR_EXPORT");
         if (trial % 4 == 1) setenv("EMSAR_HIP_FRAG_ROWS", "3072", 1);          // many independently tiled fragments, several threads
         else if (trial % 4 == 2) setenv("EMSAR_HIP_FRAG_ROWS", "7000", 1);
         else unsetenv("EMSAR_HIP_FRAG_ROWS");
@@ -41,6 +36,19 @@ int main(int argc, char **argv) {
             int rc = emsar::build_tiled(n_rows, n_tx, rp.data(), ci.data(), L, merge);
             int ck = rc ? -99 : emsar::check_tiled(L, rp.data(), ci.data());
             if (rc || ck) { printf("FAIL trial %d merge %d rc %d ck %d\n", trial, merge, rc, ck); return 1; }
+            if (!L.tiles.empty()) {                                              // a descriptor that points past its arrays must be caught on the host
+                size_t last = 0;
+                for (size_t i = 0; i < L.tiles.size(); i++) if (L.tiles[i].fwd_off > L.tiles[last].fwd_off) last = i;
+                emsar::TiledLayout B = L;
+                B.tiles[last].k[B.tiles[last].n_slices - 1] += 1;                  // one forward column more than was stored
+                emsar::TiledLayout C = L;
+                C.tiles[trial % C.tiles.size()].row_base += emsar::kTileSliceRows * 4;   // row slots of another tile, or past the end
+                emsar::TiledLayout D = L;
+                D.tiles[trial % D.tiles.size()].near_n = 0; D.tiles[trial % D.tiles.size()].far_n = 0;   // ids beyond the dictionary
+                if (emsar::check_tiled_extents(B) == 0 || emsar::check_tiled_extents(C) == 0 || emsar::check_tiled_extents(D) == 0) {
+                    printf("FAIL trial %d merge %d: a bad descriptor passed the extent check\n", trial, merge); return 1;
+                }
+            }
             setenv("EMSAR_HOST_THREADS", "1", 1);                                // the layout must not depend on the thread count
             rc = emsar::build_tiled(n_rows, n_tx, rp.data(), ci.data(), L1, merge);
             if (rc || !same_layout(L, L1)) { printf("FAIL trial %d merge %d: layout depends on the thread count\n", trial, merge); return 1; }
