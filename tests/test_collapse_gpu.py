@@ -89,6 +89,17 @@ def test_edge_cases_and_errors(dev):
         dev.collapse_rows(50, rp, np.concatenate(rows).astype(np.int32))       # tid out of range
 
 
+def test_mostly_unique_rows_outgrow_the_optimistic_table(dev):
+    """The table is sized for one segment per four reads first; when (nearly) every row is a segment of its own the probe
+    chains overrun, the call starts over with the worst-case table, and the result is the same."""
+    rng = np.random.default_rng(5)
+    n = 60000
+    ci = rng.integers(0, 2 ** 20, size=3 * n).astype(np.int32)           # 3 random ids of a million per row: no two rows alike
+    rp = np.arange(0, 3 * n + 1, 3, dtype=np.uint64)
+    got = _same(dev, 2 ** 20, rp, ci)
+    assert got[4].n_unique > 0.99 * n and got[4].table_slots >= n
+
+
 def test_full_hash_collisions_are_resolved_by_comparison(monkeypatch):
     """Test hook EMSAR_HIP_COLLAPSE_WEAK_HASH: every row of one length gets the same two hashes and the same table tag, so
     each insert walks a probe chain of unrelated rows and must tell them apart by comparing the id multisets."""
