@@ -87,6 +87,9 @@ struct emsar_hip_ctx {
     double zero_cut = 0.0;       // emsar_em_params.zero_cut of the current solve
     bool use_graph = true;       // replay check_every cycles of the streaming solve from one hipGraph (EMSAR_HIP_GRAPH=0: launch each kernel)
     int64_t graph_launches = 0;  // of the last solve (debug: EMSAR_HIP_DEBUG)
+    bool det = false;            // deterministic mode (emsar_hip_set_deterministic / EMSAR_HIP_DETERMINISTIC): fixed-point sums, kernels_common.hpp
+    double fx_mass = 0.0, fx_ll = 0.0;   // its scales for the current sample (upload_sample)
+    double *d_sqpart = nullptr;  // per-workgroup partial sums of the SQUAREM vector kernels [4][kSqPart]
     int update_grid = 256;       // workgroups of k_update (EMSAR_HIP_UPDATE_GRID)
     int sq_grid = 256;           // workgroups of the SQUAREM vector kernels (EMSAR_HIP_SQ_GRID)
     int tiled_multi = 1;         // EMSAR_HIP_TILED_MULTI 1: two tiles per workgroup (k_pass_tiled_multi) above kPairMinTiles tiles, else one
@@ -158,6 +161,9 @@ void free_structure(emsar_hip_ctx *ctx) {
     ctx->have_structure = ctx->have_sample = false;
 }
 
+// the fixed-point scales the EM kernels get (zeros = plain FP64 atomics; scatter passes always)
+inline Fx fx_of(const emsar_hip_ctx *ctx, int mode = MODE_EM) { return (ctx->det && mode != MODE_SCATTER) ? Fx{ctx->fx_mass, ctx->fx_ll} : Fx{0.0, 0.0}; }
+
 // one pass of the chosen layout.  mode: MODE_EM / MODE_EM_LL / MODE_SCATTER
 int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, double *ll_out, bool rows_only = false /* the folded rows' likelihood terms are added by the caller */) {
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
@@ -166,10 +172,10 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
             dim3 grid((unsigned)ctx->n_tiles), block(kTiledThreads);
 #define LAUNCH_T(WT, MD)                                                                                          \
     hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, ctx->d_tiles, ctx->d_fwd, ctx->d_bwd,   \
-                       ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out)
+                       ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out, fx_of(ctx, mode))
 #define LAUNCH_PN(WT, MD, NN)                                                                                     \
     hipLaunchKernelGGL((k_pass_tiled_multi<WT, MD, NN>), dim3((unsigned)((ctx->n_tiles + NN - 1) / NN)), block, lds, ctx->stream, ctx->d_tiles,  \
-                       (int)ctx->n_tiles, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, theta, acc, ll_out)
+                       (int)ctx->n_tiles, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, theta, acc, ll_out, fx_of(ctx, mode))
 #define LAUNCH_P(WT, MD) LAUNCH_PN(WT, MD, 2)
             if (mode == MODE_SCATTER) LAUNCH_T(false, MODE_SCATTER);
             else if (!ctx->weighted && (ctx->tiled_multi >= 2 || (ctx->tiled_multi == 1 && ctx->n_tiles > kPairMinTiles))) {
@@ -189,7 +195,7 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
             dim3 grid((unsigned)std::min<int64_t>((ctx->n_left + 255) / 256, 8192)), block(256);
 #define LAUNCH_L(WT, MD)                                                                                          \
     hipLaunchKernelGGL((k_pass_csr<uint64_t, WT, MD>), grid, block, 0, ctx->stream, ctx->n_left, ctx->d_left_ptr,     \
-                       ctx->d_left_col, ctx->d_left_wgt, ctx->d_left_val, theta, acc, ll_out)
+                       ctx->d_left_col, ctx->d_left_wgt, ctx->d_left_val, theta, acc, ll_out, fx_of(ctx, mode))
             if (mode == MODE_SCATTER) LAUNCH_L(false, MODE_SCATTER);
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_L(true, MODE_EM_LL); else LAUNCH_L(true, MODE_EM); }
             else { if (mode == MODE_EM_LL) LAUNCH_L(false, MODE_EM_LL); else LAUNCH_L(false, MODE_EM); }
@@ -197,7 +203,7 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
         }
         if (mode == MODE_EM_LL && !rows_only)
             hipLaunchKernelGGL(k_single_ll, dim3(std::min(grid_for(ctx->n_tx, 256), 256)), dim3(256), 0, ctx->stream, ctx->n_tx,
-                               ctx->d_u, theta, ll_out);
+                               ctx->d_u, theta, ll_out, fx_of(ctx).ll);
         HIPCHK(hipGetLastError());
         return EMSAR_HIP_OK;
     }
@@ -206,7 +212,7 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
     dim3 grid((unsigned)std::min<int64_t>(blocks, 256 * 32)), block(256);
 #define LAUNCH_C(PT, WT, MD)                                                                                     \
     hipLaunchKernelGGL((k_pass_csr<PT, WT, MD>), grid, block, 0, ctx->stream, ctx->n_rows, (const PT *)ctx->d_row_ptr, \
-                       ctx->d_col, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out)
+                       ctx->d_col, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out, fx_of(ctx, mode))
 #define LAUNCH_CP(WT, MD) do { if (ctx->ptr64) LAUNCH_C(uint64_t, WT, MD); else LAUNCH_C(uint32_t, WT, MD); } while (0)
     if (mode == MODE_SCATTER) LAUNCH_CP(false, MODE_SCATTER);
     else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_CP(true, MODE_EM_LL); else LAUNCH_CP(true, MODE_EM); }
@@ -217,13 +223,21 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
     return EMSAR_HIP_OK;
 }
 
+// a likelihood word of the host copy of the scalars (fixed point in deterministic mode)
+inline double host_ll(const emsar_hip_ctx *ctx, int i) {
+    const double v = ctx->h_scal->ll[i].v;
+    if (!ctx->det || ctx->fx_ll == 0.0) return v;
+    long long b; memcpy(&b, &v, 8);
+    return (double)b / ctx->fx_ll;
+}
+
 // th_out = EM(th_in); ll slot receives sum R log S at th_in when want_ll
 int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_ll, int ll_slot, double abs_floor, int to_delta1 = 0) {
     int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot].v);
     if (rc) return rc;
     hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), ctx->update_grid)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
                        ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->zero_cut, ctx->d_scal,
-                       ctx->delta_mask, to_delta1);
+                       ctx->delta_mask, to_delta1, fx_of(ctx).mass);
     HIPCHK(hipGetLastError());
     return EMSAR_HIP_OK;
 }
@@ -244,13 +258,13 @@ int enqueue_cycles(emsar_hip_ctx *ctx, const emsar_em_params &p, double abs_step
         }
         // the stopping rule is measured on the first (plain) step of the cycle only (delta1_bits)
         const double *u = ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr;
-        const dim3 gv((unsigned)std::min(g, ctx->sq_grid)), bv(256);
+        const dim3 gv((unsigned)std::min(std::min(g, ctx->sq_grid), kSqPart)), bv(256);
         if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor, 1))) return rc;
         if ((rc = launch_pass(ctx, MODE_EM_LL, th[1], ctx->d_acc, &ctx->d_scal->ll[1].v, true))) return rc;
-        hipLaunchKernelGGL(k_update_p2, gv, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal);
-        hipLaunchKernelGGL(k_sq_extrap_ll, gv, bv, 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, u, th[3], ctx->d_scal);
+        hipLaunchKernelGGL(k_update_p2, gv, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal, ctx->d_sqpart, fx_of(ctx));
+        hipLaunchKernelGGL(k_sq_extrap_ll, gv, bv, 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, u, th[3], ctx->d_scal, ctx->d_sqpart, (int)gv.x, fx_of(ctx));
         if ((rc = launch_pass(ctx, MODE_EM_LL, th[3], ctx->d_acc, &ctx->d_scal->ll[2].v, true))) return rc;
-        hipLaunchKernelGGL(k_update_p3, gv, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal);
+        hipLaunchKernelGGL(k_update_p3, gv, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal, ctx->d_sqpart, (int)gv.x, fx_of(ctx));
         HIPCHK(hipGetLastError());
     }
     return EMSAR_HIP_OK;
@@ -416,6 +430,7 @@ int emsar_hip_create(emsar_hip_ctx **out, int device_id) {
     auto fail = [&](int rc) { emsar_hip_destroy(ctx); return rc; };
     if (hipSetDevice(device_id) != hipSuccess) return fail(EMSAR_HIP_ERR_NO_DEVICE);
     if (const char *e = getenv("EMSAR_HIP_GRAPH")) ctx->use_graph = atoi(e) != 0;
+    if (const char *e = getenv("EMSAR_HIP_DETERMINISTIC")) ctx->det = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     for (int i = 0; i < 2; i++)
@@ -423,9 +438,17 @@ int emsar_hip_create(emsar_hip_ctx **out, int device_id) {
             hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipMalloc(&ctx->d_scal, sizeof(Scal)) != hipSuccess) return fail(EMSAR_HIP_ERR_OOM);
+    if (hipMalloc(&ctx->d_sqpart, 4 * kSqPart * sizeof(double)) != hipSuccess) return fail(EMSAR_HIP_ERR_OOM);
+    if (hipMemset(ctx->d_sqpart, 0, 4 * kSqPart * sizeof(double)) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipHostMalloc((void **)&ctx->h_scal, sizeof(Scal), hipHostMallocDefault) != hipSuccess) return fail(EMSAR_HIP_ERR_OOM);
     // both pass kernels may need more than the default dynamic-LDS limit
     *out = ctx;
+    return EMSAR_HIP_OK;
+}
+
+int emsar_hip_set_deterministic(emsar_hip_ctx *ctx, int on) {
+    if (!ctx) return EMSAR_HIP_ERR_ARG;
+    ctx->det = on != 0;
     return EMSAR_HIP_OK;
 }
 
@@ -434,7 +457,7 @@ void emsar_hip_destroy(emsar_hip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_structure(ctx);
-    dfree(ctx->d_scal);
+    dfree(ctx->d_scal); dfree(ctx->d_sqpart);
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -580,7 +603,14 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
     free_sets(ctx);
     try {
         ctx->h_wgt.resize((size_t)n_rows);
-        for (int64_t r = 0; r < n_rows; r++) ctx->h_wgt[(size_t)r] = weight_of(r);
+        int64_t total_w = 0;
+        for (int64_t r = 0; r < n_rows; r++) { const int32_t x = weight_of(r); ctx->h_wgt[(size_t)r] = x; total_w += x; }
+        // deterministic mode: no transcript is assigned more reads than the sample holds, |sum R log S| <= N * 745
+        int e_mass = 0, e_ll = 0;
+        (void)std::frexp((double)total_w + 1.0, &e_mass);
+        (void)std::frexp(((double)total_w + 1.0) * 1024.0, &e_ll);
+        ctx->fx_mass = std::ldexp(1.0, 61 - e_mass);
+        ctx->fx_ll = std::ldexp(1.0, 61 - e_ll);
     } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
         const auto &L = ctx->TL;
@@ -696,7 +726,7 @@ int emsar_hip_run_passes(emsar_hip_ctx *ctx, int32_t n_passes, float *elapsed_ms
     HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (elapsed_ms) HIPCHK(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
-    if (last_ll) *last_ll = ctx->h_scal->ll[0].v;
+    if (last_ll) *last_ll = host_ll(ctx, 0);
     return EMSAR_HIP_OK;
 }
 
@@ -785,7 +815,7 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
     hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal, 0.0, 0);
     if ((rc = launch_pass(ctx, MODE_EM_LL, th[0], ctx->d_acc, &ctx->d_scal->ll[0].v))) return rc;
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)n * 8, ctx->stream));
-    hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, ctx->stream, n, th[0], ctx->d_den, &ctx->d_scal->ll[3].v);
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, ctx->stream, n, th[0], ctx->d_den, &ctx->d_scal->ll[3].v);
     HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(fpkm_out, th[0], (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -812,7 +842,7 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
         stats->iters = iters + set_max;
         stats->converged = converged;
         stats->final_delta = delta;
-        stats->loglik = ctx->h_scal->ll[0].v + ctx->loglik_const - ctx->h_scal->ll[3].v;
+        stats->loglik = host_ll(ctx, 0) + ctx->loglik_const - ctx->h_scal->ll[3].v;
         stats->kernel_ms = ms + (use_sets ? ms_sets : 0.0f);
         stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         stats->bytes_per_pass = ctx->bytes_formula;
@@ -932,7 +962,7 @@ int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
     const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
     HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<false, MODE_EM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_pass_tiled<false, MODE_EM, true>), dim3((unsigned)ctx->n_tiles), dim3(kTiledThreads), lds, ctx->stream, ctx->d_tiles,
-                       ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].v, d);
+                       ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].v, Fx{0.0, 0.0}, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
     std::vector<unsigned long long> h(nw * 8);

@@ -38,7 +38,7 @@ typedef struct {
     const char *rsh_path, *outdir, *prefix;
     char **aln; int n_aln;
     emsar_aln_opts ao;
-    int n_round, delta, print_segments, verbose, accel, set_mode, device_collapse;
+    int n_round, delta, print_segments, verbose, accel, set_mode, device_collapse, no_deterministic;
     double tol, count_floor, zero_cut, abs_step; int max_iter;
     const char *stats_json;
     const char *rsh_cache;      /* NULL = off, "" = <rsh>.bin, else the path */
@@ -214,6 +214,7 @@ static void *worker_main(void *a) {
     }
     if (w->worker < w->cfg->n_aln) parse_start(&slot[c], w, w->worker);
     int rc = crc ? crc : emsar_hip_create(&ctx, w->device);
+    if (rc == 0) rc = emsar_hip_set_deterministic(ctx, !w->cfg->no_deterministic);     /* the streamed part of a solve: same bytes every run */
     if (rc == 0) rc = emsar_hip_upload_structure(ctx, w->rsh->n_rows, w->rsh->n_tx, w->rsh->row_ptr, w->rsh->col_idx, EMSAR_LAYOUT_AUTO);
     if (rc == 0) rc = emsar_hip_upload_euma(ctx, w->rsh->euma, w->rsh->nfl);     /* once per rsh: compute_adjEUMA runs on the device */
     if (rc) fprintf(stderr, "GPU %d: %s\n", w->device, emsar_hip_strerror(rc));
@@ -258,6 +259,8 @@ static void usage(const char *a0) {
             "      --abs-step <x>        components that move by less than x FPKM per pass count as converged (default 1e-13; 0 = off)\n"
             "      --rsh-cache[=file]    read the parsed index from a binary cache (default <rshfile>.bin), write it after a text parse\n"
             "      --streaming-only      do not split the problem into connected sets (every pass streams the whole matrix)\n"
+            "      --no-deterministic    streaming passes with floating atomics (run-to-run differences in the last digits) instead of\n"
+            "                            the fixed-point sums that make two runs of the same input print the same bytes\n"
             "      --device-collapse     reads with two or more transcripts are merged into weighted segments on the GPU\n"
             "                            (emsar_hip_collapse_rows) instead of one index lookup per read on the host; same counts\n"
             "      --gpus <n> / --devices <a,b,..> (-M: one worker per entry, ids may repeat) / --device <d> / --plain /\n"
@@ -278,7 +281,7 @@ int main(int argc, char **argv) {
         {"print_segments", no_argument, 0, 'g'}, {"multisample", no_argument, 0, 'M'}, {"SAM", no_argument, 0, 'S'}, {"BAM", no_argument, 0, 'B'},
         {"verbose", no_argument, 0, 'v'}, {"no_verbose", no_argument, 0, 'q'}, {"gpus", required_argument, 0, 1000},
         {"device", required_argument, 0, 1001}, {"plain", no_argument, 0, 1002}, {"stats-json", required_argument, 0, 1003},
-        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005}, {"rsh-cache", optional_argument, 0, 1006}, {"zero-cut", required_argument, 0, 1007}, {"abs-step", required_argument, 0, 1008}, {"devices", required_argument, 0, 1009}, {"device-collapse", no_argument, 0, 1010},
+        {"count-floor", required_argument, 0, 1004}, {"streaming-only", no_argument, 0, 1005}, {"rsh-cache", optional_argument, 0, 1006}, {"zero-cut", required_argument, 0, 1007}, {"abs-step", required_argument, 0, 1008}, {"devices", required_argument, 0, 1009}, {"device-collapse", no_argument, 0, 1010}, {"no-deterministic", no_argument, 0, 1011},
         {"maxfraglen", required_argument, 0, 'F'}, {"minfraglen", required_argument, 0, 'f'}, {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "vqPs:p:F:f:n:e:d:gMSBk:i:I:", lo, NULL)) != -1) {
@@ -309,6 +312,7 @@ int main(int argc, char **argv) {
             case 1007: cfg.zero_cut = atof(optarg); break;
             case 1008: cfg.abs_step = atof(optarg); break;
             case 1010: cfg.device_collapse = 1; break;
+            case 1011: cfg.no_deterministic = 1; break;
             case 1009: {
                 const char *q = optarg;
                 while (*q && n_dev_map < 64) {

@@ -35,6 +35,32 @@ __device__ __forceinline__ void lds_add_f64(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// ---- deterministic mode (emsar_hip_set_deterministic) ------------------------------------------------------------------
+// Floating atomics make a sum depend on the order in which its terms arrive.  In deterministic mode every sum that workgroups
+// share is kept as a 64-bit INTEGER in fixed point (integer adds commute: any arrival order gives the same bits) at a scale
+// fixed per sample:
+//   * the M-step accumulators hold MASS, theta_t * sum_c m_ct R_c / S_c -- the reads assigned to t -- which is bounded by the
+//     sample's total weight N whatever theta is: scale fx.mass = 2^(61 - ceil(log2(N + 1))), a resolution of N * 2^-61 reads;
+//   * the log-likelihood sums are bounded by N * 745: scale fx.ll.
+// fx.mass == 0 switches the mode off (plain FP64 atomics).  The sums inside one lane and the DPP / LDS reductions of one
+// workgroup are in program order either way.
+struct Fx { double mass, ll; };
+__device__ __forceinline__ void atomic_add_i64(double *p, long long v) {
+    __hip_atomic_fetch_add(reinterpret_cast<long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lds_add_i64(double *p, long long v) {
+    __hip_atomic_fetch_add(reinterpret_cast<long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// a likelihood partial sum of one workgroup -> the shared word (fixed point when fx_ll != 0)
+__device__ __forceinline__ void ll_add(double *ll_out, double t, double fx_ll) {
+    if (fx_ll != 0.0) atomic_add_i64(ll_out, __double2ll_rn(t * fx_ll));
+    else atomic_add_f64(ll_out, t);
+}
+// the value of such a word
+__device__ __forceinline__ double ll_value(const double *p, double fx_ll) {
+    return fx_ll != 0.0 ? (double)__double_as_longlong(*p) / fx_ll : *p;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;

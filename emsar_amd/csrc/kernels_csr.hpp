@@ -11,7 +11,7 @@ template <typename PTR, bool WEIGHTED, int MODE>
 __global__ __launch_bounds__(256) void k_pass_csr(int64_t n_rows, const PTR *__restrict__ row_ptr,
                                                   const int32_t *__restrict__ col, const int32_t *__restrict__ wgt,
                                                   const double *__restrict__ rowval, const double *__restrict__ theta,
-                                                  double *__restrict__ acc, double *__restrict__ ll_out) {
+                                                  double *__restrict__ acc, double *__restrict__ ll_out, Fx fx) {
     __shared__ double red[4];
     double ll = 0.0;
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) {
@@ -27,12 +27,17 @@ __global__ __launch_bounds__(256) void k_pass_csr(int64_t n_rows, const PTR *__r
             w = live ? rw / S : 0.0;
             if (MODE == MODE_EM_LL && live) ll += rw * log(S);
         }
-        if (w != 0.0)
-            for (uint64_t k = b; k < e; k++) atomic_add_f64(&acc[col[k]], w);
+        if (w != 0.0) {
+            if (MODE != MODE_SCATTER && fx.mass != 0.0) {        // deterministic mode: mass in fixed point (kernels_common.hpp)
+                for (uint64_t k = b; k < e; k++) { const int32_t t = col[k]; atomic_add_i64(&acc[t], __double2ll_rn(w * theta[t] * fx.mass)); }
+            } else {
+                for (uint64_t k = b; k < e; k++) atomic_add_f64(&acc[col[k]], w);
+            }
+        }
     }
     if (MODE == MODE_EM_LL) {
         double t = block_sum<256>(ll, red);
-        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
+        if (threadIdx.x == 0 && t != 0.0) ll_add(ll_out, t, fx.ll);
     }
 }
 

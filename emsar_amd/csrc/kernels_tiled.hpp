@@ -99,10 +99,23 @@ __device__ __forceinline__ void fwd_sum_regs(const int4 (&q)[8], int n, unsigned
     }
 }
 
+// a lane's finished column sum -> the tile's LDS accumulator.  Deterministic mode (fx != 0, wave-uniform): the sum times theta of
+// the slot (the LDS dictionary sits kTiledDictPad doubles below the accumulators) is the mass of the column's rows, added as a
+// fixed-point integer -- the four waves of the tile reach a slot in any order, the bits are the same.
+__device__ __forceinline__ void tile_acc_add(double *acc_w, unsigned off, double part, double fx) {
+    double *p = reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + off);
+    if (fx != 0.0) lds_add_i64(p, __double2ll_rn(part * *(p - kTiledDictPad) * fx));
+    else lds_add_f64(p, part);
+}
+__device__ __forceinline__ void tile_acc_flush(double *acc, int tid, double v, double fx) {
+    if (fx != 0.0) { const long long iv = __double_as_longlong(v); if (iv != 0) atomic_add_i64(&acc[tid], iv); }
+    else if (v != 0.0) atomic_add_f64(&acc[tid], v);
+}
+
 // M-step of up to 8 backward segments of one lane ({column, 11 row ids} each).  A lane's segments are consecutive
 // in column order: the running sum stays in a register and goes to the LDS accumulator when the column changes.
 template <int BATCH = 12>
-__device__ __forceinline__ void bwd_sum_regs(const int4 (&q)[8], int n, unsigned ws_base, double *acc_w, unsigned &cur, double &part) {
+__device__ __forceinline__ void bwd_sum_regs(const int4 (&q)[8], int n, unsigned ws_base, double *acc_w, unsigned &cur, double &part, double fx) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         if (j < n) {
@@ -135,7 +148,7 @@ __device__ __forceinline__ void bwd_sum_regs(const int4 (&q)[8], int n, unsigned
                 sum = (s0 + s1) + (s2 + s3);
             }
             if (col != cur) {
-                if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
+                if (part != 0.0) tile_acc_add(acc_w, cur, part, fx);
                 cur = col; part = 0.0;
             }
             part += sum;
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
                                                               const int32_t *__restrict__ wgt,    // per row slot
                                                               const double *__restrict__ rowval,  // per row slot (MODE_SCATTER)
                                                               const double *__restrict__ theta, double *__restrict__ acc,
-                                                              double *__restrict__ ll_out, unsigned long long *stamps = nullptr) {
+                                                              double *__restrict__ ll_out, Fx fx, unsigned long long *stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *th_w = lds;                     // [960]
     double *acc_w = lds + kTiledDictPad;    // [960]
@@ -287,13 +300,13 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
         for (int j0 = 0; j0 < m; j0 += 8) {
             const int n0 = m - j0 < 8 ? m - j0 : 8;
             if (j0) load8_clamped(B, b + (size_t)j0 * 64, n0);
-            bwd_sum_regs(B, n0, ws_base, acc_w, cur, part);
+            bwd_sum_regs(B, n0, ws_base, acc_w, cur, part, fx.mass);
         }
-        if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
+        if (part != 0.0) tile_acc_add(acc_w, cur, part, fx.mass);
         for (unsigned q = lane; q < coo_n; q += 64) {
             const unsigned p = __builtin_nontemporal_load(&coo[coo_base + q]);
             const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
-            if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + ((p >> 16) << 3)), v);
+            if (v != 0.0) tile_acc_add(acc_w, (p >> 16) << 3, v, fx.mass);
         }
     } else if (STAMP) ts[3] = stamp_now();
     if (STAMP) ts[4] = stamp_now();
@@ -304,8 +317,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     for (int i = 0; i < 4; i++) {
         const int d = threadIdx.x + i * kTiledThreads;
         if (d < nd) {
-            const double v = acc_w[d];
-            if (v != 0.0) atomic_add_f64(&acc[tid_d[i]], v);
+            tile_acc_flush(acc, tid_d[i], acc_w[d], fx.mass);
         }
     }
     if (STAMP && lane == 0) {   // [tile][wave][5 phases]: issue+dictionary, barrier, E, M, barrier
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     }
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);
-        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
+        if (threadIdx.x == 0 && t != 0.0) ll_add(ll_out, t, fx.ll);
     }
 }
 
@@ -400,29 +412,28 @@ __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], siz
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], const uint32_t *coo, const double *w_s, double *acc_w, int lane) {
+__device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], const uint32_t *coo, const double *w_s, double *acc_w, int lane, double fx) {
     const unsigned ws_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(w_s));
     unsigned cur = 0xFFFFFFFFu;
     double part = 0.0;
     for (int j0 = 0; j0 < W.m; j0 += 8) {
         const int n0 = W.m - j0 < 8 ? W.m - j0 : 8;
         if (j0) load8_clamped(B, W.b + (size_t)j0 * 64, n0);
-        bwd_sum_regs<6>(B, n0, ws_base, acc_w, cur, part);
+        bwd_sum_regs<6>(B, n0, ws_base, acc_w, cur, part, fx);
     }
-    if (part != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + cur), part);
+    if (part != 0.0) tile_acc_add(acc_w, cur, part, fx);
     for (unsigned q = lane; q < W.coo_n; q += 64) {
         const unsigned p = __builtin_nontemporal_load(&coo[W.coo_base + q]);
         const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
-        if (v != 0.0) lds_add_f64(reinterpret_cast<double *>(reinterpret_cast<char *>(acc_w) + ((p >> 16) << 3)), v);
+        if (v != 0.0) tile_acc_add(acc_w, (p >> 16) << 3, v, fx);
     }
 }
-__device__ __forceinline__ void tile_flush(int nd, const int (&tid_d)[4], const double *acc_w, double *acc) {
+__device__ __forceinline__ void tile_flush(int nd, const int (&tid_d)[4], const double *acc_w, double *acc, double fx) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int d = threadIdx.x + i * kTiledThreads;
         if (d < nd) {
-            const double v = acc_w[d];
-            if (v != 0.0) atomic_add_f64(&acc[tid_d[i]], v);
+            tile_acc_flush(acc, tid_d[i], acc_w[d], fx);
         }
     }
 }
@@ -430,7 +441,7 @@ __device__ __forceinline__ void tile_flush(int nd, const int (&tid_d)[4], const 
 struct TileEnv {            // per-launch constants of the multi-tile kernel
     const Tile *tiles; int n_tiles, stride;
     const uint32_t *fwd, *bwd, *coo; const int32_t *far_tid, *wgt; const double *theta; double *acc;
-    double *th_w, *acc_w, *w_s; int lane, wave;
+    double *th_w, *acc_w, *w_s; int lane, wave; double fx;
 };
 // stage I of N: tile `it` is in the registers (A, B in flight or landed, dictionary values in thv); while it is being
 // worked on, tile it + stride is requested into the registers as they fall free.  Straight-line code, no loop: hipcc
@@ -452,10 +463,10 @@ __device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const Tile
         if (Wn.has_slice) load8_clamped(A, Wn.e, Wn.k < 8 ? Wn.k : 8);
         tile_dict_issue(Tn, Wn.nd, V.far_tid, V.theta, thv, tidn);
     }
-    if (W.has_slice) tile_m_step(W, B, V.coo, V.w_s, V.acc_w, V.lane);
+    if (W.has_slice) tile_m_step(W, B, V.coo, V.w_s, V.acc_w, V.lane, V.fx);
     if (has_next && Wn.has_slice && Wn.m > 0) load8_clamped(B, Wn.b, Wn.m < 8 ? Wn.m : 8);
     __syncthreads();
-    tile_flush(W.nd, tid, V.acc_w, V.acc);
+    tile_flush(W.nd, tid, V.acc_w, V.acc, V.fx);
     if constexpr (I + 1 < N) {
         if (has_next) tiled_stage<WEIGHTED, MODE, I + 1, N>(V, in, Tn, Wn, A, B, thv, tidn, ll);
     }
@@ -466,12 +477,12 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Til
                                                                     const uint32_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
                                                                     const int32_t *__restrict__ far_tid, const int32_t *__restrict__ wgt,
                                                                     const double *__restrict__ theta, double *__restrict__ acc,
-                                                                    double *__restrict__ ll_out) {
+                                                                    double *__restrict__ ll_out, Fx fx) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double red[kTiledThreads / 64];
     TileEnv V;
     V.tiles = tiles; V.n_tiles = n_tiles; V.stride = (int)gridDim.x; V.fwd = fwd; V.bwd = bwd; V.coo = coo; V.far_tid = far_tid; V.wgt = wgt;
-    V.theta = theta; V.acc = acc;
+    V.theta = theta; V.acc = acc; V.fx = fx.mass;
     V.lane = threadIdx.x & 63;
     V.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     V.th_w = lds; V.acc_w = lds + kTiledDictPad; V.w_s = lds + 2 * kTiledDictPad + V.wave * kTiledWr;
@@ -489,12 +500,12 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Til
     tiled_stage<WEIGHTED, MODE, 0, N>(V, (int)blockIdx.x, T, W, A, B, thv, tid, ll);
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);
-        if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(ll_out, t);
+        if (threadIdx.x == 0 && t != 0.0) ll_add(ll_out, t, fx.ll);
     }
 }
 
 // likelihood terms of the folded single-tid rows: sum_t u_t log theta_t
-__global__ __launch_bounds__(256) void k_single_ll(int n, const double *__restrict__ u, const double *__restrict__ theta, double *ll_out) {
+__global__ __launch_bounds__(256) void k_single_ll(int n, const double *__restrict__ u, const double *__restrict__ theta, double *ll_out, double fx_ll) {
     __shared__ double red[4];
     double s = 0.0;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(256) void k_single_ll(int n, const double *__restri
         if (c > 0.0 && x > 0.0) s += c * log(x);
     }
     double tot = block_sum<256>(s, red);
-    if (threadIdx.x == 0 && tot != 0.0) atomic_add_f64(ll_out, tot);
+    if (threadIdx.x == 0 && tot != 0.0) ll_add(ll_out, tot, fx_ll);
 }
 
 }  // namespace

@@ -7,6 +7,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // T-sized vector kernels
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double em_new_theta(double x, double a, double dn, const double *u, int t, double fx);
 __global__ void k_fill_start(int n, const double *__restrict__ den, double *__restrict__ theta) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) theta[t] = den[t] > 0.0 ? 1.0 : 0.0;  // uniform interior start; tids outside F are defined 0
@@ -18,14 +19,14 @@ __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict_
                                                 const double *__restrict__ den, const double *__restrict__ u /* folded single-tid rows, may be null */,
                                                 double *__restrict__ th_out, double abs_floor, double count_floor, double zero_cut, Scal *scal,
                                                 const uint8_t *__restrict__ kind /* non-null: only KIND_STREAMED transcripts enter the stopping rule */,
-                                                int to_delta1 /* the first (plain) step of a SQUAREM cycle: the cycle's stopping rule */) {
+                                                int to_delta1 /* the first (plain) step of a SQUAREM cycle: the cycle's stopping rule */, double fx) {
     __shared__ double red[4];
     double d = 0.0;
     const double abs_step = scal->abs_step_cur;      // written by k_cycle_begin, nobody writes it during a pass
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
         double a = acc[t], dn = den[t], x = th_in[t];
         // a row {t} contributes R/theta_t to acc_t, i.e. R to theta_t*acc_t: added analytically (TILED layout)
-        double y = dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
+        double y = em_new_theta(x, a, dn, u, t, fx);
         th_out[t] = y;
         acc[t] = 0.0;
         double fl = abs_floor;
@@ -71,16 +72,33 @@ __global__ void k_scal_init(Scal *s) {
 //   k_sq_extrap_ll thx = th0 + 2 s r + s^2 v  (Varadhan & Roland 2008, S3: s = |r|/|v| clamped to [1, stepmax]); components that
 //                 would leave the interior keep the plain EM value th2; s <= 1.01 -> thx = th2; + sum u log thx -> ll[2]
 //   k_update_p3   th0 = accepted ? EM(thx) : th2, accepted iff F(thx) >= F(th1), F = ll - sum theta*den; step bounds x4 / :4
-__device__ __forceinline__ double em_new_theta(double x, double a, double dn, const double *u, int t) {
-    return dn > 0.0 ? (u ? (x > 0.0 ? (x * a + u[t]) / dn : 0.0) : x * a / dn) : 0.0;
+// a = the accumulator word of t: sum_c m_ct R_c / S_c, or in deterministic mode (fx != 0) the MASS theta_t * that sum in fixed point
+__device__ __forceinline__ double em_new_theta(double x, double a, double dn, const double *u, int t, double fx) {
+    const double mass = fx != 0.0 ? (double)__double_as_longlong(a) / fx : x * a;
+    return dn > 0.0 ? (u ? (x > 0.0 ? (mass + u[t]) / dn : 0.0) : mass / dn) : 0.0;
+}
+// Reductions of the SQUAREM cycle that every workgroup of the NEXT kernel needs (|r|^2, |v|^2, sum theta*den): each workgroup of the
+// producer writes its partial sum to its own word, each workgroup of the consumer adds the words up in the same fixed order -- no
+// same-address atomics (hundreds of them cost ~12 ns each), and the same bits in every run.
+constexpr int kSqPart = 1024;        // most workgroups of a SQUAREM vector kernel (ctx->sq_grid is clamped to it)
+__device__ __forceinline__ double sq_sum(const double *__restrict__ part, int n, double *red) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    const double tot = block_sum<256>(s, red);      // valid in thread 0: handed to everybody through LDS
+    if (threadIdx.x == 0) red[0] = tot;
+    __syncthreads();
+    const double all = red[0];
+    __syncthreads();
+    return all;
 }
 __global__ __launch_bounds__(256) void k_update_p2(int n, const double *__restrict__ th0, const double *__restrict__ th1, double *__restrict__ acc,
-                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th2, Scal *scal) {
+                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th2, Scal *scal,
+                                                   double *__restrict__ part, Fx fx) {
     __shared__ double red[4];
     double r2 = 0, v2 = 0, p1 = 0, l1 = 0;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
         const double x = th1[t], dn = den[t];
-        const double y = em_new_theta(x, acc[t], dn, u, t);
+        const double y = em_new_theta(x, acc[t], dn, u, t, fx.mass);
         th2[t] = y;
         acc[t] = 0.0;
         const double r = x - th0[t], v = (y - x) - r;
@@ -91,16 +109,17 @@ __global__ __launch_bounds__(256) void k_update_p2(int n, const double *__restri
     double b = block_sum<256>(v2, red); __syncthreads();
     double c = block_sum<256>(p1, red); __syncthreads();
     double d = block_sum<256>(l1, red);
-    if (threadIdx.x == 0) {
-        atomic_add_f64(&scal->sr2.v, a); atomic_add_f64(&scal->sv2.v, b); atomic_add_f64(&scal->pen1.v, c);
-        if (d != 0.0) atomic_add_f64(&scal->ll[1].v, d);
+    if (threadIdx.x == 0) {       // |r|^2, |v|^2, sum theta*den: one word per workgroup, summed in a fixed order by the kernels that use them (sq_sum)
+        part[blockIdx.x] = a; part[kSqPart + blockIdx.x] = b; part[2 * kSqPart + blockIdx.x] = c;
+        if (d != 0.0) ll_add(&scal->ll[1].v, d, fx.ll);
     }
 }
 __global__ __launch_bounds__(256) void k_sq_extrap_ll(int n, const double *__restrict__ th0, const double *__restrict__ th1,
                                                       const double *__restrict__ th2, const double *__restrict__ den, const double *__restrict__ u,
-                                                      double *__restrict__ thx, Scal *scal) {
+                                                      double *__restrict__ thx, Scal *scal, double *__restrict__ part, int n_part, Fx fx) {
     __shared__ double red[4];
-    double s = scal->sv2.v > 0.0 ? sqrt(scal->sr2.v / scal->sv2.v) : 1.0;
+    const double sr2 = sq_sum(part, n_part, red), sv2 = sq_sum(part + kSqPart, n_part, red);
+    double s = sv2 > 0.0 ? sqrt(sr2 / sv2) : 1.0;
     s = fmin(fmax(s, 1.0), scal->stepmax);
     const bool extrap = s > 1.01;
     double px = 0, lx = 0;
@@ -118,18 +137,21 @@ __global__ __launch_bounds__(256) void k_sq_extrap_ll(int n, const double *__res
     double p = block_sum<256>(px, red); __syncthreads();
     double l = block_sum<256>(lx, red);
     if (threadIdx.x == 0) {
-        atomic_add_f64(&scal->penx.v, p);
-        if (l != 0.0) atomic_add_f64(&scal->ll[2].v, l);
-        if (blockIdx.x == 0) scal->s_used = extrap ? s : 1.0;
+        part[3 * kSqPart + blockIdx.x] = p;
+        if (l != 0.0) ll_add(&scal->ll[2].v, l, fx.ll);
+        if (blockIdx.x == 0) { scal->s_used = extrap ? s : 1.0; scal->sr2 = sr2; scal->sv2 = sv2; }
     }
 }
 __global__ __launch_bounds__(256) void k_update_p3(int n, const double *__restrict__ thx, const double *__restrict__ th2, double *__restrict__ acc,
-                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th0, Scal *scal) {
+                                                   const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th0, Scal *scal,
+                                                   const double *__restrict__ part, int n_part, Fx fx) {
+    __shared__ double red[4];
     const double s = scal->s_used;
     const bool extrap = s > 1.0;
-    const bool ok = !extrap || (scal->ll[2].v - scal->penx.v >= scal->ll[1].v - scal->pen1.v);
+    const double pen1 = sq_sum(part + 2 * kSqPart, n_part, red), penx = sq_sum(part + 3 * kSqPart, n_part, red);
+    const bool ok = !extrap || (ll_value(&scal->ll[2].v, fx.ll) - penx >= ll_value(&scal->ll[1].v, fx.ll) - pen1);
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
-        const double y = em_new_theta(thx[t], acc[t], den[t], u, t);
+        const double y = em_new_theta(thx[t], acc[t], den[t], u, t, fx.mass);
         acc[t] = 0.0;
         th0[t] = ok ? y : th2[t];
     }
@@ -139,6 +161,7 @@ __global__ __launch_bounds__(256) void k_update_p3(int n, const double *__restri
         else { scal->accepted++; }
         if ((ok ? s : 1.0) >= sm) sm *= 4.0;
         scal->stepmax = sm;
+        scal->pen1 = pen1; scal->penx = penx;
     }
 }
 
@@ -196,11 +219,13 @@ __global__ __launch_bounds__(1024) void k_sum(int n, const double *__restrict__ 
     double tot = block_sum<1024>(s, red);
     if (threadIdx.x == 0) *out = *out + tot;
 }
-__global__ __launch_bounds__(256) void k_dot(int n, const double *__restrict__ x, const double *__restrict__ y, double *out) {
-    __shared__ double red[4];
-    int t = blockIdx.x * 256 + threadIdx.x;
-    double s = block_sum<256>(t < n ? x[t] * y[t] : 0.0, red);
-    if (threadIdx.x == 0) atomic_add_f64(out, s);
+// sum x*y: ONE workgroup, fixed order (the penalty term of the printed log-likelihood)
+__global__ __launch_bounds__(1024) void k_dot(int n, const double *__restrict__ x, const double *__restrict__ y, double *out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int t = threadIdx.x; t < n; t += 1024) s += x[t] * y[t];
+    const double tot = block_sum<1024>(s, red);
+    if (threadIdx.x == 0) *out = tot;
 }
 // print_FPKMfinal arithmetic (emsar_functions.c:3203-3207): TPM, iReadcount, Round_off
 __global__ void k_normalise(int n, const double *__restrict__ mean, const double *__restrict__ ieuma, double nreads_m,

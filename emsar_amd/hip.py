@@ -20,6 +20,7 @@ SYMBOLS = [
     "emsar_hip_reset_theta", "emsar_hip_set_theta", "emsar_hip_get_theta", "emsar_hip_run_passes",
     "emsar_hip_ieuma", "emsar_hip_normalise", "emsar_hip_get_info",
     "emsar_hip_layout_selfcheck_tiled", "emsar_hip_sets_selfcheck", "emsar_hip_upload_euma", "emsar_hip_adj_euma", "emsar_hip_collapse_rows",
+    "emsar_hip_set_deterministic",
 ]
 
 
@@ -92,6 +93,8 @@ def load_library():
     L.emsar_hip_normalise.argtypes = [vp, f64p, f64p, C.c_int64, f64p, f64p, i32p]
     L.emsar_hip_get_info.argtypes = [vp, C.POINTER(Info)]
     L.emsar_hip_layout_selfcheck_tiled.argtypes = [C.c_int64, C.c_int32, u64p, i32p, C.c_int, C.POINTER(Info)]
+    L.emsar_hip_set_deterministic.argtypes = [vp, C.c_int]
+    L.emsar_hip_set_deterministic.restype = C.c_int
     L.emsar_hip_collapse_rows.argtypes = [vp, C.c_int64, C.c_int32, u64p, i32p, i32p, C.POINTER(C.c_int64), u64p, i32p, i32p, i32p,
                                           C.POINTER(CollapseStats)]
     L.emsar_hip_upload_euma.argtypes = [vp, i32p, C.c_int32]
@@ -253,6 +256,10 @@ class EmsarHip:
         out = np.zeros(self.n_tx)
         self._chk(self._L.emsar_hip_get_theta(self._h, _p(out, C.c_double)), "get_theta")
         return out
+
+    def set_deterministic(self, on=True):
+        """Fixed-point sums in the streaming passes: two solves of the same input are bit-identical (include/emsar_hip.h)."""
+        self._chk(self._L.emsar_hip_set_deterministic(self._h, 1 if on else 0), "set_deterministic")
 
     def run_passes(self, n, want_loglik=False):
         ms = C.c_float(0)

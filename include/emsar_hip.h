@@ -178,6 +178,15 @@ int emsar_hip_collapse_rows(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx, co
                             const int32_t *row_weight, int64_t *n_unique_out, uint64_t *row_ptr_out, int32_t *col_idx_out,
                             int32_t *weight_out, int32_t *row_map_out, emsar_hip_collapse_stats *stats);
 
+/* ---- deterministic mode ------------------------------------------------------------------------------------------
+ * The streaming passes add with floating atomics, so two runs of the same solve agree to ~1e-9 relative, not bit for bit (the
+ * per-set solver of set_mode 0 has no atomics and is reproducible either way).  With the mode on, every sum that workgroups share
+ * is kept as a 64-bit integer in fixed point (integer adds commute): the M-step accumulators hold the reads assigned to a
+ * transcript at a resolution of N * 2^-61 reads (N = the sample's total weight), the log-likelihood sums at N * 2^-51, the
+ * SQUAREM norms are added up in a fixed order.  Two solves of the same input are then bit-identical, whatever the layout's
+ * tile order.  Costs a few percent of a pass.  Default: off, or EMSAR_HIP_DETERMINISTIC=1 in the environment at create time. */
+int emsar_hip_set_deterministic(emsar_hip_ctx *ctx, int on);
+
 /* ---- introspection ------------------------------------------------------------------------------ */
 typedef struct {
     int64_t n_rows, nnz;

@@ -239,6 +239,62 @@ def test_full_size_properties_cfg2(dev):
         assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
 
 
+def _avail_gib():
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable:"):
+            return int(line.split()[1]) / 2 ** 20
+    return 0.0
+
+
+def _full_size_properties(dev, s, passes, csr_passes):
+    """Properties that need no oracle, at BASELINE's full size: mass conservation after every M-step, monotone F, finite
+    non-negative theta, and layout independence against the CSR kernel (other row order, other number of adds)."""
+    n_reads, den = s["n_reads"], s["den"]
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
+    dev.upload_sample(None, None, den)
+    prev_ll = -np.inf
+    for _ in range(passes):
+        _, ll = dev.run_passes(1, want_loglik=True)                # ll is evaluated at the pass input
+        th = dev.get_theta()
+        assert np.isfinite(th).all() and (th >= 0).all()
+        assert abs((th * den).sum() - n_reads) <= 1e-9 * n_reads
+        assert ll >= prev_ll - 1e-9 * abs(ll)
+        prev_ll = ll
+    dev.reset_theta()
+    dev.run_passes(csr_passes)
+    a = dev.get_theta()
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_CSR)
+    dev.upload_sample(None, None, den)
+    dev.run_passes(csr_passes)
+    b = dev.get_theta()
+    assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-300)
+    # round trip of the encode: what the device stores decodes to the input (host self check on the same arrays)
+    return a
+
+
+def test_full_size_properties_cfg3(dev):
+    """BASELINE config 3 at full size (50M reads x 200k transcripts, nnz 251M): about 6 GiB of host arrays."""
+    if _avail_gib() < 24:
+        pytest.skip("needs 24 GiB of free host memory")
+    s = synth.make_config("cfg3", 1.0)
+    _full_size_properties(dev, s, passes=4, csr_passes=3)
+    # a solve to the bench's tolerance conserves the mass and lands where the merged-row layout lands
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
+    dev.upload_sample(None, None, s["den"])
+    th, st = dev.solve(set_mode=1, max_iter=20000, accel=1, tol=1e-6, abs_floor=0.01, check_every=4)       # bench.py's solve_to_convergence
+    assert st.converged == 1, (st.iters, st.final_delta)
+    assert abs((th * s["den"]).sum() - s["n_reads"]) <= 1e-9 * s["n_reads"]
+
+
+def test_full_size_properties_cfg5(dev):
+    """BASELINE config 5 at full size (200M reads x 250k transcripts, 20 alignments per read: nnz 4.0e9 -> 16 GB of column ids alone;
+    generating it and laying it out needs about 100 GiB of host memory): gated on the memory the box has."""
+    if _avail_gib() < 120:
+        pytest.skip("needs 120 GiB of free host memory")
+    s = synth.make_config("cfg5", 1.0)
+    _full_size_properties(dev, s, passes=2, csr_passes=2)
+
+
 @pytest.mark.parametrize("multi", ["0", "2"])
 def test_loglik_of_unweighted_rows_at_extreme_theta(monkeypatch, multi):
     """The unweighted TILED kernels take the log of a product of six row sums instead of six logs; a product that
