@@ -11,7 +11,9 @@ is the barrier and the max-over-ranks of the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the TILED layout, k_pass_tiled /
 k_pass_tiled_multi<2> (+ the small k_update that shares the pass): algorithmic bytes per pass /
-mean device time per pass measured with HIP events on the library's own stream.  `cpu_baseline` times the CPU oracle's OpenMP EM pass on the same
+mean device time per pass measured with HIP events on the library's own stream (`frac_actual`: the same with the HBM bytes the PMC
+counters saw, profiles/traffic.json).  After the timed passes: `solve_to_convergence` (the same matrix solved to --solve) and
+`fpkm_delta_vs_oracle` (a down-scaled config 3 solved by both).  `cpu_baseline` times the CPU oracle's OpenMP EM pass on the same
 matrix on this box's host cores (rank 0, N=1 only).
 """
 import argparse

@@ -797,7 +797,7 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
             HIPCHK(hipStreamSynchronize(ctx->stream));
             unsigned long long bits = p.accel ? ctx->h_scal->delta1_bits : ctx->h_scal->delta_bits;
             memcpy(&delta, &bits, 8);
-            if (!std::isfinite(delta)) { ctx->err = "non-finite theta"; return EMSAR_HIP_ERR_NUMERIC; }
+            if (!std::isfinite(delta) || ctx->h_scal->bad) { ctx->err = "non-finite theta"; return EMSAR_HIP_ERR_NUMERIC; }
             if (delta < p.tol) { converged = 1; break; }
         }
     }
@@ -831,6 +831,7 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
             const SetStat &q = ctx->h_sstat[i];
             set_max = std::max(set_max, q.passes); set_sum += q.passes;
             if (!q.converged) set_unconv++;
+            if (!std::isfinite(q.delta)) { ctx->err = "non-finite theta in a connected set"; return EMSAR_HIP_ERR_NUMERIC; }
             if (q.delta > delta) delta = q.delta;
         }
     if (set_unconv) converged = 0;

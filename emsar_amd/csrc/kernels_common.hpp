@@ -25,6 +25,7 @@ struct Scal {
     double sum_a, sum_b;          // generic reductions (normalise)
     long long passes;             // EM passes enqueued before the current cycle (k_cycle_begin keeps it: the cycle may replay from a hipGraph)
     double abs_step_cur;          // emsar_em_params.abs_step scaled to the pass count of the current cycle (0 = rule off)
+    unsigned int bad;             // set (never cleared during a solve) when an update met NaN / Inf: the state may look finite again later
 };
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) {

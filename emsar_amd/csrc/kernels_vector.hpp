@@ -33,6 +33,9 @@ __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict_
         if (count_floor > 0.0 && dn > 0.0) fl = fmax(fl, count_floor / dn);    // floor expressed in inferred reads
         double dd = fabs(y - x) / (fabs(y) + fl);
         if (!(dd == dd)) dd = __builtin_huge_val();  // NaN -> +inf so that the host sees it
+        // ... also when the next check is many passes away: an overflowed theta is NaN one pass later and 0 the pass after
+        // (NaN > 0 is false in the update), and an all-zero answer looks converged
+        if (dd == __builtin_huge_val() || !(y - y == 0.0)) scal->bad = 1u;
         if (y < zero_cut && y <= x) dd = 0.0;        // below the print quantum and still falling: prints as 0.000000 either way
         if (fabs(y - x) < abs_step) dd = 0.0;         // moves by less than abs_step per pass (emsar_em_params.abs_step)
         if (kind && kind[t] != emsar::KIND_STREAMED) dd = 0.0;
@@ -62,7 +65,7 @@ __global__ void k_cycle_begin(Scal *s, double abs_step_base, int passes_in_cycle
 }
 __global__ void k_scal_init(Scal *s) {
     s->stepmax = 1.0; s->s_used = 1.0; s->accepted = 0; s->rejected = 0; s->sum_a = s->sum_b = 0.0;
-    s->passes = 0; s->abs_step_cur = 0.0;
+    s->passes = 0; s->abs_step_cur = 0.0; s->bad = 0u;
 }
 
 // ---- the SQUAREM cycle of the streaming solve with the O(T) work folded into the three update kernels ----

@@ -147,6 +147,23 @@ def test_error_paths(dev):
     assert e.value.status == -2
 
 
+@pytest.mark.parametrize("set_mode", [0, 1])
+def test_non_finite_theta_is_reported_not_returned(set_mode):
+    """EMSAR_HIP_ERR_NUMERIC (-6): effective lengths so small that theta = reads / den leaves the double range.  The solve must
+    say so instead of handing back inf / NaN (the reference would print them)."""
+    s = synth.make_matrix(n_tx=300, n_reads=20000, law="human", xfam=0.02, seed=4)
+    den = np.full(s["n_tx"], 1e-307)                               # reads / den > 1.8e308 for every expressed transcript: the first M-step overflows
+    with EmsarHip(0) as ctx:
+        ctx.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
+        ctx.upload_sample(None, None, den)
+        with pytest.raises(EmsarHipError) as e:
+            ctx.solve(set_mode=set_mode, max_iter=200, tol=1e-9)
+        assert e.value.status == -6
+        ctx.upload_sample(None, None, s["den"])                     # the context is still usable
+        th, st = ctx.solve(set_mode=set_mode, max_iter=5000, tol=1e-8)
+        assert np.isfinite(th).all() and st.converged == 1
+
+
 @pytest.mark.parametrize("name,scale", [("cfg2", 0.05), ("cfg3", 0.004), ("cfg5", 0.0005)])
 def test_synthetic_read_level_matches_oracle(dev, name, scale):
     s = synth.make_config(name, scale)                          # cfg5: heavy repeats, rows of 50-100 tids
