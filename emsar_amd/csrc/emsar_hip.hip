@@ -38,6 +38,7 @@
 #include "kernels_tiled.hpp"
 #include "kernels_vector.hpp"
 #include "kernels_sets.hpp"
+#include "kernels_cluster.hpp"
 
 // ==================================================================================================
 // context
@@ -48,8 +49,8 @@ struct emsar_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    hipStream_t side[2] = {nullptr, nullptr};     // the 256- and 512-thread classes of the set solver run next to the 64-thread one
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};     // the 256- and 512-thread classes of the set solver and the clusters run next to the 64-thread class
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     std::string err;
     // structure
     bool have_structure = false, have_sample = false;
@@ -102,6 +103,13 @@ struct emsar_hip_ctx {
     emsar::ResidentSets RS;      // index vectors are freed after the upload, counters stay
     emsar::SetDesc *d_sdesc[emsar::kSetClasses] = {nullptr, nullptr, nullptr};
     SetStat *d_sstat = nullptr; SetStat *h_sstat = nullptr; int64_t n_sstat = 0;
+    // workgroup-cluster sets (kernels_cluster.hpp)
+    emsar::ClusterDesc *d_cdesc = nullptr; uint32_t *d_cblk = nullptr, *d_crp = nullptr, *d_ccp = nullptr, *d_cpart = nullptr;
+    uint16_t *d_cent = nullptr, *d_ccrow = nullptr; int32_t *d_cg_tid = nullptr; double *d_cg_u = nullptr, *d_crow_w = nullptr, *d_cscratch = nullptr;
+    unsigned *d_cbar = nullptr;          // [2 n]: barrier words, then abort words
+    ClusterStat *d_cstat = nullptr, *h_cstat = nullptr;
+    int64_t n_cstat = 0;
+    hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // around the cluster launches (stats)
     int32_t *d_g_tid = nullptr; double *d_g_u = nullptr, *d_row_w = nullptr, *d_usum = nullptr;
     uint16_t *d_srp = nullptr, *d_sent = nullptr, *d_scp = nullptr, *d_scrow = nullptr;
     uint8_t *d_kind = nullptr;
@@ -139,6 +147,11 @@ void free_sets(emsar_hip_ctx *ctx) {
     dfree(ctx->d_srp); dfree(ctx->d_sent); dfree(ctx->d_scp); dfree(ctx->d_scrow); dfree(ctx->d_kind);
     ctx->d_g_tid = nullptr; ctx->d_g_u = ctx->d_row_w = ctx->d_usum = nullptr;
     ctx->d_srp = ctx->d_sent = ctx->d_scp = ctx->d_scrow = nullptr; ctx->d_kind = nullptr;
+    dfree(ctx->d_cdesc); dfree(ctx->d_cblk); dfree(ctx->d_crp); dfree(ctx->d_ccp); dfree(ctx->d_cpart); dfree(ctx->d_cent); dfree(ctx->d_ccrow);
+    dfree(ctx->d_cg_tid); dfree(ctx->d_cg_u); dfree(ctx->d_crow_w); dfree(ctx->d_cscratch); dfree(ctx->d_cbar); dfree(ctx->d_cstat);
+    if (ctx->h_cstat) { (void)hipHostFree(ctx->h_cstat); ctx->h_cstat = nullptr; }
+    ctx->d_cdesc = nullptr; ctx->d_cblk = ctx->d_crp = ctx->d_ccp = ctx->d_cpart = nullptr; ctx->d_cent = ctx->d_ccrow = nullptr;
+    ctx->d_cg_tid = nullptr; ctx->d_cg_u = ctx->d_crow_w = ctx->d_cscratch = nullptr; ctx->d_cbar = nullptr; ctx->d_cstat = nullptr; ctx->n_cstat = 0;
     ctx->RS = emsar::ResidentSets(); ctx->sets_ready = false; ctx->n_sstat = 0;
 }
 
@@ -356,6 +369,29 @@ int ensure_sets_impl(emsar_hip_ctx *ctx) {
         HIPCHK(hipFuncSetAttribute((const void *)k_solve_sets<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)emsar::kSetLdsCap[1]));
         HIPCHK(hipFuncSetAttribute((const void *)k_solve_sets<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)emsar::kSetLdsCap[2]));
     }
+    const int64_t nc = S.n_cluster_sets();
+    if (nc > 0) {
+        auto &CL = S.CL;
+        HIPCHK(up((void **)&ctx->d_cdesc, CL.desc.data(), CL.desc.size() * sizeof(emsar::ClusterDesc)));
+        HIPCHK(up((void **)&ctx->d_cblk, CL.blk_set.data(), CL.blk_set.size() * 4));
+        HIPCHK(up((void **)&ctx->d_crp, CL.rp.data(), CL.rp.size() * 4));
+        HIPCHK(up((void **)&ctx->d_ccp, CL.cp.data(), CL.cp.size() * 4));
+        HIPCHK(up((void **)&ctx->d_cpart, CL.part.data(), CL.part.size() * 4));
+        HIPCHK(up((void **)&ctx->d_cent, CL.ent.data(), CL.ent.size() * 2));
+        HIPCHK(up((void **)&ctx->d_ccrow, CL.crow.data(), CL.crow.size() * 2));
+        HIPCHK(up((void **)&ctx->d_cg_tid, CL.g_tid.data(), CL.g_tid.size() * 4));
+        HIPCHK(up((void **)&ctx->d_cg_u, CL.g_u.data(), CL.g_u.size() * 8));
+        HIPCHK(up((void **)&ctx->d_crow_w, CL.row_w.data(), CL.row_w.size() * 8));
+        HIPCHK(hipMalloc(&ctx->d_cscratch, std::max<size_t>((size_t)CL.scratch_doubles, 2) * 8));
+        HIPCHK(hipMalloc(&ctx->d_cbar, (size_t)nc * 2 * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&ctx->d_cstat, (size_t)nc * sizeof(ClusterStat)));
+        HIPCHK(hipHostMalloc((void **)&ctx->h_cstat, (size_t)nc * sizeof(ClusterStat), hipHostMallocDefault));
+        ctx->n_cstat = nc;
+        HIPCHK(hipFuncSetAttribute((const void *)k_solve_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)emsar::kClusterLdsCap));
+        // only the sizes are needed from here on
+        std::vector<uint32_t>().swap(CL.rp); std::vector<uint32_t>().swap(CL.cp); std::vector<uint16_t>().swap(CL.ent); std::vector<uint16_t>().swap(CL.crow);
+        std::vector<int32_t>().swap(CL.g_tid); std::vector<double>().swap(CL.g_u); std::vector<double>().swap(CL.row_w);
+    }
     // the device copies are the only ones needed from here on (desc sizes and counters stay)
     std::vector<int32_t>().swap(S.g_tid); std::vector<double>().swap(S.g_u); std::vector<double>().swap(S.row_w);
     std::vector<uint16_t>().swap(S.rp); std::vector<uint16_t>().swap(S.ent); std::vector<uint16_t>().swap(S.cp); std::vector<uint16_t>().swap(S.crow);
@@ -379,12 +415,32 @@ int solve_resident_sets(emsar_hip_ctx *ctx, const SetSolveParams &P, double *the
         hipLaunchKernelGGL(k_solve_sets<TH>, dim3((unsigned)S.desc[C].size()), dim3(TH), S.max_lds[C], ST,                   \
                            ctx->d_sdesc[C], ctx->d_g_tid, ctx->d_g_u, ctx->d_row_w, ctx->d_srp, ctx->d_sent, ctx->d_scp,     \
                            ctx->d_scrow, ctx->d_den, theta, ctx->d_sstat + off[C], P);
-    for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0));
+    for (int i = 0; i < 3; i++) HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0));
+    if (ctx->n_cstat > 0) {
+        // The clusters, on a stream of their own.  Every workgroup of a launch must be resident at once (they wait for each other at
+        // the cluster barriers): at most one workgroup per CU per launch -- each asks for most of a CU's LDS --, whole sets only.
+        hipDeviceProp_t prop;
+        int n_cu = 64;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        HIPCHK(hipMemsetAsync(ctx->d_cbar, 0, (size_t)ctx->n_cstat * 2 * sizeof(unsigned), ctx->side[2]));
+        HIPCHK(hipEventRecord(ctx->ev_c0, ctx->side[2]));
+        const auto &D = S.CL.desc;
+        size_t first = 0;
+        while (first < D.size()) {
+            size_t last = first, wgs = 0;
+            while (last < D.size() && (wgs == 0 || wgs + D[last].g <= (size_t)n_cu)) wgs += D[last++].g;
+            hipLaunchKernelGGL(k_solve_cluster, dim3((unsigned)wgs), dim3(emsar::kClusterThreads), S.CL.max_lds, ctx->side[2], ctx->d_cdesc, ctx->d_cblk,
+                               D[first].blk0, ctx->d_cg_tid, ctx->d_cg_u, ctx->d_crow_w, ctx->d_crp, ctx->d_cent, ctx->d_ccp, ctx->d_ccrow, ctx->d_cpart,
+                               ctx->d_cscratch, ctx->d_cbar, ctx->d_cbar + ctx->n_cstat, ctx->d_den, theta, ctx->d_cstat, P);
+            first = last;
+        }
+        HIPCHK(hipEventRecord(ctx->ev_c1, ctx->side[2]));
+    }
     LAUNCH_S(2, 512, ctx->side[1])      // the big ones first: they are the fewest and the longest per pass
     LAUNCH_S(1, 256, ctx->side[0])
     LAUNCH_S(0, 64, ctx->stream)
 #undef LAUNCH_S
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         HIPCHK(hipEventRecord(ctx->ev_join[i], ctx->side[i]));
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
     }
@@ -433,7 +489,8 @@ int emsar_hip_create(emsar_hip_ctx **out, int device_id) {
     if (const char *e = getenv("EMSAR_HIP_DETERMINISTIC")) ctx->det = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
-    for (int i = 0; i < 2; i++)
+    if (hipEventCreate(&ctx->ev_c0) != hipSuccess || hipEventCreate(&ctx->ev_c1) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
+    for (int i = 0; i < 3; i++)
         if (hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
     if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
@@ -463,7 +520,9 @@ void emsar_hip_destroy(emsar_hip_ctx *ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    for (int i = 0; i < 2; i++) {
+    if (ctx->ev_c0) (void)hipEventDestroy(ctx->ev_c0);
+    if (ctx->ev_c1) (void)hipEventDestroy(ctx->ev_c1);
+    for (int i = 0; i < 3; i++) {
         if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
     }
@@ -809,6 +868,8 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
         if ((rc = solve_resident_sets(ctx, P, th[0]))) return rc;
         if (ctx->n_sstat > 0)
             HIPCHK(hipMemcpyAsync(ctx->h_sstat, ctx->d_sstat, (size_t)ctx->n_sstat * sizeof(SetStat), hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->n_cstat > 0)
+            HIPCHK(hipMemcpyAsync(ctx->h_cstat, ctx->d_cstat, (size_t)ctx->n_cstat * sizeof(ClusterStat), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipEventRecord(ctx->ev2, ctx->stream));
     // F at the returned point: one likelihood-only pass (not counted in iters)
@@ -834,6 +895,17 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
             if (!std::isfinite(q.delta)) { ctx->err = "non-finite theta in a connected set"; return EMSAR_HIP_ERR_NUMERIC; }
             if (q.delta > delta) delta = q.delta;
         }
+    int32_t cl_max = 0;
+    if (use_sets)
+        for (int64_t i = 0; i < ctx->n_cstat; i++) {
+            const ClusterStat &q = ctx->h_cstat[i];
+            if (q.aborted) { ctx->err = "a workgroup cluster gave up waiting at its barrier"; return EMSAR_HIP_ERR_HIP; }
+            cl_max = std::max(cl_max, q.passes); set_sum += q.passes;
+            if (!q.converged) set_unconv++;
+            if (!std::isfinite(q.delta)) { ctx->err = "non-finite theta in a connected set"; return EMSAR_HIP_ERR_NUMERIC; }
+            if (q.delta > delta) delta = q.delta;
+        }
+    set_max = std::max(set_max, cl_max);
     if (set_unconv) converged = 0;
     if (stats) {
         float ms = 0, ms_sets = 0;
@@ -857,6 +929,9 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
             stats->set_passes_sum = set_sum;
             stats->sets_build_ms = ctx->sets_build_ms;
             stats->sets_kernel_ms = ms_sets;
+            stats->sets_cluster = (int32_t)ctx->n_cstat;
+            stats->cluster_passes_max = cl_max;
+            if (ctx->n_cstat > 0) { float mc = 0; HIPCHK(hipEventElapsedTime(&mc, ctx->ev_c0, ctx->ev_c1)); stats->cluster_kernel_ms = mc; }
         }
     }
     return EMSAR_HIP_OK;
@@ -1017,7 +1092,8 @@ int emsar_hip_sets_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_p
             for (int c = 0; c < emsar::kSetClasses; c++) { o->sets_resident[c] = (int64_t)S.desc[c].size(); o->max_lds_bytes[c] = (int64_t)S.max_lds[c]; }
             o->sets_streamed = S.n_streamed_sets;
             o->tids_closed = S.n_closed_tids; o->tids_resident = S.n_resident_tids; o->tids_streamed = S.n_streamed_tids;
-            o->rows_in = S.rows_in; o->rows_stored = S.rows_stored;
+            o->rows_in = S.rows_in; o->rows_stored = S.rows_stored + S.CL.rows_stored;
+            o->sets_cluster = S.n_cluster_sets(); o->tids_cluster = S.CL.n_tids; o->max_lds_cluster = (int64_t)S.CL.max_lds;
         }
         return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 200 + rc;
     } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }     // nothing may leave the C ABI as an exception

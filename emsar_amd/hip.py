@@ -42,7 +42,7 @@ class EmStats(C.Structure):
                 ("stored_bytes_per_pass", C.c_int64),
                 ("sets_resident", C.c_int32), ("sets_streamed", C.c_int32), ("set_passes_max", C.c_int32),
                 ("sets_unconverged", C.c_int32), ("set_passes_sum", C.c_int64), ("sets_build_ms", C.c_double),
-                ("sets_kernel_ms", C.c_double)]
+                ("sets_kernel_ms", C.c_double), ("sets_cluster", C.c_int32), ("cluster_passes_max", C.c_int32), ("cluster_kernel_ms", C.c_double)]
 
 
 class CollapseStats(C.Structure):
@@ -53,7 +53,8 @@ class CollapseStats(C.Structure):
 class SetsInfo(C.Structure):
     _fields_ = [("n_components", C.c_int64), ("sets_resident", C.c_int64 * 3), ("max_lds_bytes", C.c_int64 * 3),
                 ("sets_streamed", C.c_int64), ("tids_closed", C.c_int64), ("tids_resident", C.c_int64),
-                ("tids_streamed", C.c_int64), ("rows_in", C.c_int64), ("rows_stored", C.c_int64)]
+                ("tids_streamed", C.c_int64), ("rows_in", C.c_int64), ("rows_stored", C.c_int64),
+                ("sets_cluster", C.c_int64), ("tids_cluster", C.c_int64), ("max_lds_cluster", C.c_int64)]
 
 
 class Info(C.Structure):

@@ -103,7 +103,10 @@ typedef struct {
     int32_t sets_unconverged; /* resident sets that hit max_iter */
     int64_t set_passes_sum;   /* EM passes summed over the resident sets */
     double  sets_build_ms;    /* host time spent finding and packing the sets (once per upload_sample) */
-    double  sets_kernel_ms;   /* device time of the resident-set kernels */
+    double  sets_kernel_ms;   /* device time of the resident-set kernels (clusters included) */
+    int32_t sets_cluster;     /* connected sets solved by a cluster of 2-8 workgroups inside one launch (too large for one workgroup's LDS) */
+    int32_t cluster_passes_max; /* EM passes of the slowest of them (set_passes_max covers them too) */
+    double  cluster_kernel_ms;  /* device time from the first to the last cluster launch */
 } emsar_em_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
@@ -218,6 +221,7 @@ typedef struct {
     int64_t sets_streamed;       /* sets too large for one workgroup */
     int64_t tids_closed, tids_resident, tids_streamed;
     int64_t rows_in, rows_stored; /* weighted multi-transcript rows before / after merging identical ones */
+    int64_t sets_cluster, tids_cluster, max_lds_cluster;   /* sets packed for a cluster of workgroups, their transcripts, the largest LDS footprint of one of their workgroups */
 } emsar_hip_sets_info;
 int emsar_hip_sets_selfcheck(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                              const int32_t *row_weight, emsar_hip_sets_info *info_out);

@@ -34,8 +34,8 @@ def test_header_symbols_are_exported(lib):
 def test_struct_sizes_match_header(lib):
     # plain C layout, no padding surprises between the header and the ctypes mirror
     assert C.sizeof(H.EmParams) == 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 4 + 4
-    assert C.sizeof(H.EmStats) == 4 + 4 + 8 * 4 + 8 * 2 + 4 * 4 + 8 * 3
-    assert C.sizeof(H.SetsInfo) == 8 * 13
+    assert C.sizeof(H.EmStats) == 4 + 4 + 8 * 4 + 8 * 2 + 4 * 4 + 8 * 3 + 4 + 4 + 8
+    assert C.sizeof(H.SetsInfo) == 8 * 16
     assert C.sizeof(H.Info) == 8 * 2 + 4 * 2 + 8 * 4 + 4 * 2 + 8 * 2
 
 

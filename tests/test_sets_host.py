@@ -22,14 +22,25 @@ def test_toy_split():
     assert d["n_components"] == 2 and d["tids_resident"] == 5
 
 
-def test_classes_and_streamed_sets():
+def test_classes_clusters_and_streamed_sets(monkeypatch):
     n_tx, rp, ci, w = family_matrix([2, 3, 5, 8, 40, 200, 900, 2500, 6000], seed=3)
+    monkeypatch.setenv("EMSAR_HIP_CLUSTER", "1")                             # the cluster solver is opt-in (slower per pass than streaming)
     d = sets_selfcheck(n_tx, rp, ci, w)
-    assert d["tids_closed"] + d["tids_resident"] + d["tids_streamed"] == n_tx
-    assert d["sets_streamed"] >= 1 and d["tids_streamed"] >= 6000          # 5 vectors of 6000 doubles > 156 KiB
+    assert d["tids_closed"] + d["tids_resident"] + d["tids_cluster"] + d["tids_streamed"] == n_tx
+    # 8 vectors of 2500 or 6000 doubles do not fit one workgroup's 156 KiB: those two families go to clusters of workgroups
+    assert d["sets_cluster"] == 2 and d["tids_cluster"] >= 8000 and d["sets_streamed"] == 0
+    assert 0 < d["max_lds_cluster"] <= 156 * 1024
     assert d["sets_resident"][0] >= 3 and d["sets_resident"][1] >= 1 and d["sets_resident"][2] >= 1
     assert d["max_lds_bytes"][0] <= 6 * 1024 and d["max_lds_bytes"][1] <= 48 * 1024 and d["max_lds_bytes"][2] <= 156 * 1024
     assert d["rows_stored"] < d["rows_in"]                                   # duplicates merged
+    monkeypatch.delenv("EMSAR_HIP_CLUSTER")                                  # default: they are streamed, as in round 1
+    d = sets_selfcheck(n_tx, rp, ci, w)
+    assert d["sets_cluster"] == 0 and d["sets_streamed"] == 2 and d["tids_streamed"] >= 8000
+    # a component beyond a cluster's reach (20 000 transcripts: the whole point no longer fits a workgroup's LDS) is still streamed
+    monkeypatch.setenv("EMSAR_HIP_CLUSTER", "1")
+    n_tx, rp, ci, w = family_matrix([20000, 3000], seed=4)
+    d = sets_selfcheck(n_tx, rp, ci, w)
+    assert d["sets_streamed"] == 1 and d["tids_streamed"] >= 19000 and d["sets_cluster"] == 1
 
 
 def test_no_reads_and_empty():
@@ -48,8 +59,8 @@ def test_random_block_matrices(seed):
     sizes = list(rng.integers(1, 60, size=200)) + [int(rng.integers(300, 1500))]
     n_tx, rp, ci, w = family_matrix(sizes, rows_per_tid=int(rng.integers(1, 6)), seed=seed)
     d = sets_selfcheck(n_tx, rp, ci, w if seed % 2 else None)
-    assert d["tids_closed"] + d["tids_resident"] + d["tids_streamed"] == n_tx
-    assert d["n_components"] == sum(d["sets_resident"]) + d["sets_streamed"]
+    assert d["tids_closed"] + d["tids_resident"] + d["tids_cluster"] + d["tids_streamed"] == n_tx
+    assert d["n_components"] == sum(d["sets_resident"]) + d["sets_cluster"] + d["sets_streamed"]
 
 
 def test_giant_component_is_detected_early():

@@ -76,7 +76,7 @@ int main(int argc, char **argv) {
         emsar::build_sets(n_rows, n_tx, rp.data(), ci.data(), wp, S);
         int ck = emsar::check_sets(n_rows, n_tx, rp.data(), ci.data(), wp, S);
         if (ck) { printf("FAIL sets trial %d ck %d\n", trial, ck); return 1; }
-        if (S.n_closed_tids + S.n_resident_tids + S.n_streamed_tids != n_tx) { printf("FAIL sets census %d\n", trial); return 1; }
+        if (S.n_closed_tids + S.n_resident_tids + S.n_streamed_tids + S.CL.n_tids != n_tx) { printf("FAIL sets census %d\n", trial); return 1; }
     }
     printf("ok\n");
     return 0;
