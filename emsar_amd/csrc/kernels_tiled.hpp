@@ -19,7 +19,8 @@ namespace {
 constexpr int kTiledThreads = 256;                       // 4 wavefronts = 4 slices
 constexpr int kRPL = emsar::kRowsPerLane;                 // 12 rows per lane = twelve 10-bit ids per int4
 constexpr int kTiledWr = emsar::kTileSliceRows + 8;       // w_r of one slice (768) + the zero padding row
-constexpr int kTiledDictPad = emsar::kTileDict + 1;       // 960 slots incl. the zero slot
+constexpr int kTiledDictPad = emsar::kDictEntries;        // 960 table entries: 120 blocks x 8 subset sums (entry 0 = the empty subset = 0)
+constexpr int kBlk = emsar::kBlk;
 constexpr int kTiledLdsDoubles = 2 * kTiledDictPad + emsar::kTileSlices * kTiledWr;   // 40,192 B: 4 workgroups per CU
 
 __device__ __forceinline__ double lds_at(const double *base, unsigned byte_off) {
@@ -107,9 +108,55 @@ __device__ __forceinline__ void tile_acc_add(double *acc_w, unsigned off, double
     if (fx != 0.0) lds_add_i64(p, __double2ll_rn(part * *(p - kTiledDictPad) * fx));
     else lds_add_f64(p, part);
 }
-__device__ __forceinline__ void tile_acc_flush(double *acc, int tid, double v, double fx) {
-    if (fx != 0.0) { const long long iv = __double_as_longlong(v); if (iv != 0) atomic_add_i64(&acc[tid], iv); }
-    else if (v != 0.0) atomic_add_f64(&acc[tid], v);
+// ---- the dictionary of a tile: blocks of three transcripts, eight subset sums each (layout_tiled.hpp) ----
+// Thread b < 120 owns block b in both directions: it fetches the block's three theta values, writes the eight subset sums
+// T[8b + m] and clears the eight accumulators W[8b + m]; at the end of the tile it folds the eight W words into its three
+// transcripts (transcript i of the block collects the subsets that hold it) and sends them to the global accumulator.
+struct BlockDict { double th[kBlk]; int tid[kBlk]; };
+template <int MODE>
+__device__ __forceinline__ void block_dict_issue(const Tile &T, int nd, const int32_t *far_tid, const double *theta, BlockDict &D) {
+#pragma unroll
+    for (int i = 0; i < kBlk; i++) {
+        const int d = (int)threadIdx.x * kBlk + i;
+        D.th[i] = 0.0; D.tid[i] = -1;
+        if (threadIdx.x < emsar::kDictBlocks && d < nd) {
+            D.tid[i] = d < (int)T.near_n ? T.lo + d : __builtin_nontemporal_load(&far_tid[T.far_off + (d - (int)T.near_n)]);
+            if (MODE != MODE_SCATTER) D.th[i] = theta[D.tid[i]];
+        }
+    }
+}
+__device__ __forceinline__ void block_dict_store(const BlockDict &D, double *th_w, double *acc_w) {
+    if (threadIdx.x < emsar::kDictBlocks) {
+        double *t = th_w + threadIdx.x * 8, *a = acc_w + threadIdx.x * 8;
+        const double x0 = D.th[0], x1 = D.th[1], x2 = D.th[2];
+        t[0] = 0.0; t[1] = x0; t[2] = x1; t[3] = x0 + x1; t[4] = x2; t[5] = x0 + x2; t[6] = x1 + x2; t[7] = (x0 + x1) + x2;
+#pragma unroll
+        for (int m = 0; m < 8; m++) a[m] = 0.0;
+    }
+}
+__device__ __forceinline__ void block_dict_flush(const BlockDict &D, const double *th_w, const double *acc_w, double *acc, double fx) {
+    if (threadIdx.x >= emsar::kDictBlocks || D.tid[0] < 0) return;
+    const double *a = acc_w + threadIdx.x * 8;
+    if (fx != 0.0) {
+        // deterministic mode: W[e] holds, as an integer, the MASS of entry e (sum of w_r T[e] fx over its rows: tile_acc_add);
+        // the column sum of the entry is that over T[e], transcript i gets theta_i times the sum over the subsets that hold it
+        const double *t = th_w + threadIdx.x * 8;
+        double c[8];
+#pragma unroll
+        for (int m = 1; m < 8; m++) { const double tm = t[m]; c[m] = tm > 0.0 ? (double)__double_as_longlong(a[m]) / tm : 0.0; }
+        const double s[kBlk] = {(c[1] + c[3]) + (c[5] + c[7]), (c[2] + c[3]) + (c[6] + c[7]), (c[4] + c[5]) + (c[6] + c[7])};
+#pragma unroll
+        for (int i = 0; i < kBlk; i++) {
+            if (D.tid[i] < 0) continue;
+            const long long iv = __double2ll_rn(t[1 << i] * s[i]);
+            if (iv != 0) atomic_add_i64(&acc[D.tid[i]], iv);
+        }
+    } else {
+        const double s[kBlk] = {(a[1] + a[3]) + (a[5] + a[7]), (a[2] + a[3]) + (a[6] + a[7]), (a[4] + a[5]) + (a[6] + a[7])};
+#pragma unroll
+        for (int i = 0; i < kBlk; i++)
+            if (D.tid[i] >= 0 && s[i] != 0.0) atomic_add_f64(&acc[D.tid[i]], s[i]);
+    }
 }
 
 // M-step of up to 8 backward segments of one lane ({column, 11 row ids} each).  A lane's segments are consecutive
@@ -211,17 +258,8 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
 
     // ---- issue every global load this wave needs first, in the order of use: dictionary values, 8 forward columns,
     //      8 backward segments.  One HBM round trip per tile; the rest of the pass touches LDS only.
-    double thv[4];
-    int tid_d[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        thv[i] = 0.0; tid_d[i] = -1;
-        if (d < nd) {
-            tid_d[i] = d < (int)T.near_n ? T.lo + d : __builtin_nontemporal_load(&far_tid[T.far_off + (d - (int)T.near_n)]);
-            if (MODE != MODE_SCATTER) thv[i] = theta[tid_d[i]];
-        }
-    }
+    BlockDict D;
+    block_dict_issue<MODE>(T, nd, far_tid, theta, D);
     int4 A[8], B[8];
     const int4 *e = nullptr, *b = nullptr;
     int k = 0, m = 0;
@@ -242,12 +280,8 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
         if (MODE != MODE_SCATTER) load8_clamped(A, e, k < 8 ? k : 8);
         if (m > 0) load8_clamped(B, b, m < 8 ? m : 8);
     }
-    // ---- phase 0: dictionary into LDS (slot nd is the zero slot) ----
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        if (d <= nd) { th_w[d] = thv[i]; acc_w[d] = 0.0; }
-    }
+    // ---- phase 0: the table of subset sums into LDS, the accumulators cleared ----
+    block_dict_store(D, th_w, acc_w);
     if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;      // padding row of this wave's slice
     if (STAMP) ts[1] = stamp_now();
     __syncthreads();
@@ -312,14 +346,8 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     if (STAMP) ts[4] = stamp_now();
     __syncthreads();
     if (STAMP) ts[5] = stamp_now();
-    // ---- F: flush the dictionary ----
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        if (d < nd) {
-            tile_acc_flush(acc, tid_d[i], acc_w[d], fx.mass);
-        }
-    }
+    // ---- F: the accumulators of every block folded into its transcripts and flushed ----
+    block_dict_flush(D, th_w, acc_w, acc, fx.mass);
     if (STAMP && lane == 0) {   // [tile][wave][5 phases]: issue+dictionary, barrier, E, M, barrier
         for (int i = 0; i < 5; i++) stamps[((size_t)blockIdx.x * (kTiledThreads / 64) + wave) * 8 + i] = ts[i + 1] - ts[i];
     }
@@ -364,24 +392,6 @@ __device__ __forceinline__ TileWave tile_wave(const Tile &T, int wave, int lane,
         W.b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 4 + (size_t)boff * 256) + lane;
     }
     return W;
-}
-__device__ __forceinline__ void tile_dict_issue(const Tile &T, int nd, const int32_t *far_tid, const double *theta, double (&thv)[4], int (&tid_d)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        thv[i] = 0.0; tid_d[i] = -1;
-        if (d < nd) {
-            tid_d[i] = d < (int)T.near_n ? T.lo + d : __builtin_nontemporal_load(&far_tid[T.far_off + (d - (int)T.near_n)]);
-            thv[i] = theta[tid_d[i]];
-        }
-    }
-}
-__device__ __forceinline__ void tile_dict_store(int nd, const double (&thv)[4], double *th_w, double *acc_w) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        if (d <= nd) { th_w[d] = thv[i]; acc_w[d] = 0.0; }
-    }
 }
 template <bool WEIGHTED, int MODE>
 __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], size_t slot0, const int32_t *wgt, const double *th_w, double *w_s,
@@ -428,16 +438,6 @@ __device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], con
         if (v != 0.0) tile_acc_add(acc_w, (p >> 16) << 3, v, fx);
     }
 }
-__device__ __forceinline__ void tile_flush(int nd, const int (&tid_d)[4], const double *acc_w, double *acc, double fx) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int d = threadIdx.x + i * kTiledThreads;
-        if (d < nd) {
-            tile_acc_flush(acc, tid_d[i], acc_w[d], fx);
-        }
-    }
-}
-
 struct TileEnv {            // per-launch constants of the multi-tile kernel
     const Tile *tiles; int n_tiles, stride;
     const uint32_t *fwd, *bwd, *coo; const int32_t *far_tid, *wgt; const double *theta; double *acc;
@@ -448,9 +448,10 @@ struct TileEnv {            // per-launch constants of the multi-tile kernel
 // keeps loop-carried register arrays of this size in scratch.
 template <bool WEIGHTED, int MODE, int I, int N>
 __device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const Tile &T, const TileWave &W, int4 (&A)[8], int4 (&B)[8],
-                                            double (&thv)[4], const int (&tid)[4], double &ll) {
-    // a thread rewrites only the dictionary slots it flushed at the end of the previous stage
-    tile_dict_store(W.nd, thv, V.th_w, V.acc_w);
+                                            BlockDict &D, double &ll) {
+    // a thread rewrites only the block it flushed at the end of the previous stage
+    block_dict_store(D, V.th_w, V.acc_w);
+    const BlockDict Dcur = D;                     // tids of THIS tile's block, for its flush; D is refilled for the next tile below
     const int in = it + V.stride;
     const bool has_next = (I + 1 < N) && in < V.n_tiles;
     const Tile Tn = V.tiles[has_next ? in : it];
@@ -458,17 +459,16 @@ __device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const Tile
     if (W.has_slice)
         tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)V.wave * emsar::kTileSliceRows + V.lane, V.wgt, V.th_w, V.w_s, V.lane, ll);
     const TileWave Wn = tile_wave(Tn, V.wave, V.lane, V.fwd, V.bwd);
-    int tidn[4] = {-1, -1, -1, -1};
     if (has_next) {
         if (Wn.has_slice) load8_clamped(A, Wn.e, Wn.k < 8 ? Wn.k : 8);
-        tile_dict_issue(Tn, Wn.nd, V.far_tid, V.theta, thv, tidn);
+        block_dict_issue<MODE>(Tn, Wn.nd, V.far_tid, V.theta, D);
     }
     if (W.has_slice) tile_m_step(W, B, V.coo, V.w_s, V.acc_w, V.lane, V.fx);
     if (has_next && Wn.has_slice && Wn.m > 0) load8_clamped(B, Wn.b, Wn.m < 8 ? Wn.m : 8);
     __syncthreads();
-    tile_flush(W.nd, tid, V.acc_w, V.acc, V.fx);
+    block_dict_flush(Dcur, V.th_w, V.acc_w, V.acc, V.fx);
     if constexpr (I + 1 < N) {
-        if (has_next) tiled_stage<WEIGHTED, MODE, I + 1, N>(V, in, Tn, Wn, A, B, thv, tidn, ll);
+        if (has_next) tiled_stage<WEIGHTED, MODE, I + 1, N>(V, in, Tn, Wn, A, B, D, ll);
     }
 }
 
@@ -488,16 +488,16 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Til
     V.th_w = lds; V.acc_w = lds + kTiledDictPad; V.w_s = lds + 2 * kTiledDictPad + V.wave * kTiledWr;
     const Tile T = tiles[blockIdx.x];
     const TileWave W = tile_wave(T, V.wave, V.lane, fwd, bwd);
-    double thv[4]; int tid[4];
+    BlockDict D;
     int4 A[8], B[8];
-    tile_dict_issue(T, W.nd, far_tid, theta, thv, tid);
+    block_dict_issue<MODE>(T, W.nd, far_tid, theta, D);
     if (W.has_slice) {
         load8_clamped(A, W.e, W.k < 8 ? W.k : 8);
         if (W.m > 0) load8_clamped(B, W.b, W.m < 8 ? W.m : 8);
     }
     if (V.lane < 8) V.w_s[emsar::kTileSliceRows + V.lane] = 0.0;
     double ll = 0.0;
-    tiled_stage<WEIGHTED, MODE, 0, N>(V, (int)blockIdx.x, T, W, A, B, thv, tid, ll);
+    tiled_stage<WEIGHTED, MODE, 0, N>(V, (int)blockIdx.x, T, W, A, B, D, ll);
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);
         if (threadIdx.x == 0 && t != 0.0) ll_add(ll_out, t, fx.ll);

@@ -45,16 +45,44 @@ constexpr int kTileSlices = 4;         // wavefronts per workgroup
 constexpr int kRowsPerLane = 12;       // twelve 10-bit ids per int4
 constexpr int kTileSliceRows = 64 * kRowsPerLane;   // 768
 constexpr int kTileRows = kTileSlices * kTileSliceRows;
-constexpr int kTileDict = 959;         // theta + acc windows in LDS: 2 x 7.5 KiB; +1 zero slot (5 workgroups per CU)
+// The dictionary of a tile is organised in BLOCKS of kBlk consecutive slots; a stored operand does not name one slot but a block
+// and a SUBSET of it: entry = block * 8 + mask.  The kernel's LDS table holds, for every block, the 8 subset sums of its three
+// theta values (T[block*8 + mask]), so ONE gather serves every transcript of the block that a row hits -- isoforms of a gene are
+// neighbours in tid order and reads hit several of them: 2.5 ids per entry on config 3, i.e. 2.5x fewer index bytes and LDS
+// gathers for the same matrix.  The M-step accumulates per entry value and folds the 8 words of a block into its 3 transcripts
+// when the tile is flushed.  Entry 0 (block 0, empty subset) is the padding: T[0] = 0.
+constexpr int kBlk = 3;                          // slots per block
+constexpr int kBlkEntries = 1 << kBlk;           // subset sums per block
+constexpr int kDictBlocks = 120;
+constexpr int kDictEntries = kDictBlocks * kBlkEntries;   // 960 doubles of LDS for T, 960 for the per-entry accumulators
+constexpr int kTileDict = kBlk * kDictBlocks;    // 360 transcripts per tile
 constexpr int64_t kFragRows = 1 << 21;   // sorted rows per independently tiled fragment (build_tiled)
-constexpr int kMaxRowLen = 768;        // longer rows -> leftover CSR (a row must fit one dictionary)
+constexpr int kMaxRowLen = kTileDict;  // longer rows -> leftover CSR (a row must fit one dictionary)
 constexpr int kSegRows = 11;           // row ids per backward segment (plus 1 header = 12 x 10 bit = one int4)
 constexpr int kSliceDwords = kTileSliceRows / 3;    // dwords per forward column of a slice (256 = 1 KiB)
 
 // field i (0..11) of a packed int4: dword i/3, bits 10*(i%3) .. +10
 inline void pack10(uint32_t *q, int i, uint32_t id) { q[i / 3] |= (id & 0x3FFu) << (10 * (i % 3)); }
 inline uint32_t unpack10(const uint32_t *q, int i) { return (q[i / 3] >> (10 * (i % 3))) & 0x3FFu; }
-constexpr int kDenseMin = 4;           // columns with fewer entries in a slice use the COO list
+constexpr int kDenseMin = 1;           // columns with fewer entries in a slice use the COO list (1 = none: with block entries the COO path --
+                                       // a load, an LDS read and an LDS atomic per entry -- costs more than a mostly empty segment: 4 / 2 / 1 -> 0.139 / 0.133 / 0.127 ms)
+// the entries (block * 8 + mask) of one row from its dictionary slots (any order; a slot that occurs twice -- an internal repeat
+// of the transcript -- opens a second entry of the same block: a subset holds a transcript once)
+inline void slots_to_entries(std::vector<uint32_t> &slots, std::vector<uint32_t> &ent) {
+    std::sort(slots.begin(), slots.end());
+    ent.clear();
+    int cur_b = -1;
+    uint32_t cur_m = 0;
+    for (uint32_t sl : slots) {
+        const int b = (int)(sl / (uint32_t)kBlk);
+        const uint32_t bit = 1u << (sl % (uint32_t)kBlk);
+        if (b != cur_b || (cur_m & bit)) {
+            if (cur_b >= 0) ent.push_back((uint32_t)cur_b * (uint32_t)kBlkEntries + cur_m);
+            cur_b = b; cur_m = bit;
+        } else cur_m |= bit;
+    }
+    if (cur_b >= 0) ent.push_back((uint32_t)cur_b * (uint32_t)kBlkEntries + cur_m);
+}
 constexpr int64_t kTileEntries = 65536;
 
 // vectors whose resize(n) leaves the new elements uninitialised (resize(n, v) still fills): the big index arrays are
@@ -152,19 +180,27 @@ inline int check_tiled_extents(const TiledLayout &L) {
             if (T.k[s] > kMaxRowLen) return -27;
             const size_t fw = (size_t)T.k[s] * kSliceDwords, bw = (size_t)T.m[s] * 64 * 4;
             if (foff + fw > nf || boff + bw > nb || coff + T.coo_n[s] > nc) return -28;
+            // an entry names a block and a subset of it: every slot of the subset must exist in the tile's dictionary
+            auto entry_ok = [&](uint32_t e) {
+                if (e >= (uint32_t)kDictEntries) return false;
+                const uint32_t m = e & (uint32_t)(kBlkEntries - 1), b = e >> kBlk;
+                for (int i = 0; i < kBlk; i++) if ((m >> i & 1u) && b * (uint32_t)kBlk + (uint32_t)i >= (uint32_t)nd) return false;
+                return true;
+            };
             for (size_t i = 0; i < fw; i++) {
                 const uint32_t d = L.fwd[foff + i];
-                if ((d & 0x3FFu) > (uint32_t)nd || ((d >> 10) & 0x3FFu) > (uint32_t)nd || ((d >> 20) & 0x3FFu) > (uint32_t)nd) return -29;
+                if (!entry_ok(d & 0x3FFu) || !entry_ok((d >> 10) & 0x3FFu) || !entry_ok((d >> 20) & 0x3FFu)) return -29;
             }
             for (size_t i = 0; i < bw; i += 4) {
                 const uint32_t *q = &L.bwd[boff + i];
                 bool any = false;
                 for (int w = 1; w < 12; w++) { const uint32_t rl = unpack10(q, w); if (rl > (uint32_t)kTileSliceRows) return -29; any |= rl != (uint32_t)kTileSliceRows; }
-                if (unpack10(q, 0) > (uint32_t)nd || (any && unpack10(q, 0) >= (uint32_t)nd)) return -29;
+                const uint32_t e = unpack10(q, 0);
+                if (!entry_ok(e) || (any && (e & (uint32_t)(kBlkEntries - 1)) == 0)) return -29;
             }
             for (size_t i = 0; i < T.coo_n[s]; i++) {
                 const uint32_t p = L.coo[coff + i];
-                if ((p >> 16) >= (uint32_t)nd || (p & 0xFFFFu) >= (uint32_t)kTileSliceRows) return -29;
+                if (!entry_ok(p >> 16) || ((p >> 16) & (uint32_t)(kBlkEntries - 1)) == 0 || (p & 0xFFFFu) >= (uint32_t)kTileSliceRows) return -29;
             }
             foff += fw; boff += bw; coff += T.coo_n[s];
         }
@@ -329,7 +365,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     const int64_t n_act = (int64_t)act.size();
     // Sort granularity in tid space.  A tile's dictionary must hold a block's tid range plus the rows' reach, so
     // blocks stay small; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
-    int32_t block = 512;
+    int32_t block = 96;        // the rows of one block of the sort fit one dictionary (360 transcripts) with room for their far hits;
+                               // config 3: 256 / 192 / 160 / 128 / 96 tids -> 0.145 / 0.139 / 0.136 / 0.134 / 0.124 ms per pass
     if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 900) block = v; }
     int64_t tile_rows = kTileRows;
     if (const char *e = getenv("EMSAR_HIP_TILE_ROWS")) { int v = atoi(e); if (v >= kTileSliceRows && v <= kTileRows) tile_rows = v / kTileSliceRows * kTileSliceRows; }
@@ -385,6 +422,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         std::vector<uint32_t> pairs, sorted;   // (col_local << 16) | row_in_slice
         std::vector<uint32_t> ccount, fill;
         std::vector<uint32_t> segs;            // 4 dwords per segment
+        std::vector<uint32_t> rslots, rents, rent, rent_ptr;   // one row's slots / entries; all rows' entries of the tile
         int64_t i0 = range_begin;
         int32_t tile_id = 0;
         const int64_t n_act = range_end;      // rows beyond the range belong to another fragment
@@ -448,7 +486,6 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 else { loc[(size_t)t] = near_n + (int32_t)(out.far_tid.size() - T.far_off); out.far_tid.push_back(t); }
             }
             const int nd = near_n + far_n;
-            const uint32_t zero_id = (uint32_t)nd;                         // th_w[nd] = 0
             const uint32_t pad_row = (uint32_t)kTileSliceRows;             // w_r[768] of every slice = 0
             const int64_t nrow = i1 - i0;
             T.n_slices = (uint16_t)((nrow + kTileSliceRows - 1) / kTileSliceRows);
@@ -458,53 +495,64 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             T.bwd_off = (uint64_t)out.bwd.size() * 4;
             T.coo_off = (uint32_t)out.coo.size();
             out.n_fslices += T.n_slices;
+            // the entries of every row of the tile, once (used by the forward and by the backward index)
+            rent_ptr.assign(1, 0u); rent.clear();
+            for (int64_t i = i0; i < i1; i++) {
+                const uint32_t r = perm[(size_t)i];
+                rslots.clear();
+                for (uint64_t q = row_ptr[r]; q < row_ptr[r + 1]; q++) {
+                    const int32_t d = loc[(size_t)col_idx[q]];
+                    rslots.push_back((uint32_t)d);
+                    if (d >= near_n) out.far_entries++;
+                }
+                slots_to_entries(rslots, rents);
+                rent.insert(rent.end(), rents.begin(), rents.end());
+                rent_ptr.push_back((uint32_t)rent.size());
+                out.tiled_entries += (int64_t)rents.size();
+            }
             // 3. forward slices (all of them first: the tile's forward block is contiguous).  Column j of a slice is 256
             //    dwords; row p of the slice (p = position in sorted order) is field p/64 of the int4 of lane p%64: the 64
             //    lanes of one E-step gather read 64 CONSECUTIVE sorted rows, i.e. mostly one family -- the same few
-            //    dictionary slots (LDS broadcast) or neighbouring ones (distinct banks) instead of a random spread
-            uint32_t zero_dword = zero_id | (zero_id << 10) | (zero_id << 20);
+            //    table entries (LDS broadcast) or neighbouring ones (distinct banks) instead of a random spread
             for (int s = 0; s < T.n_slices; s++) {
                 int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
                 int64_t k = 0;
-                for (int64_t i = a0; i < bnd; i++) { uint32_t r = perm[(size_t)i]; k = std::max<int64_t>(k, (int64_t)(row_ptr[r + 1] - row_ptr[r])); }
+                for (int64_t i = a0; i < bnd; i++) k = std::max<int64_t>(k, (int64_t)(rent_ptr[(size_t)(i - i0) + 1] - rent_ptr[(size_t)(i - i0)]));
                 T.k[s] = (uint16_t)k;
                 size_t base = out.fwd.size();
-                out.fwd.resize(base + (size_t)k * kSliceDwords, zero_dword);
+                out.fwd.resize(base + (size_t)k * kSliceDwords, 0u);            // entry 0 = the empty subset: padding
                 out.padded_slots += k * kTileSliceRows;
                 for (int64_t i = a0; i < bnd; i++) {
                     uint32_t r = perm[(size_t)i];
                     uint32_t in_slice = (uint32_t)(i - a0);
                     out.slot_row[(size_t)T.row_base + (size_t)s * kTileSliceRows + in_slice] = (int64_t)r;
-                    uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-                    for (uint64_t q = b; q < e; q++) {
-                        int32_t d = loc[(size_t)col_idx[q]];
+                    const uint32_t b = rent_ptr[(size_t)(i - i0)], e = rent_ptr[(size_t)(i - i0) + 1];
+                    for (uint32_t q = b; q < e; q++) {
+                        const uint32_t d = rent[q];
                         const uint32_t fl = in_slice & 63u, fi = in_slice >> 6;      // lane, field: see slot numbering above
                         uint32_t *dw = &out.fwd[base + (size_t)(q - b) * kSliceDwords + fl * 4 + fi / 3];
                         const int sh = 10 * (int)(fi % 3);
-                        *dw = (*dw & ~(0x3FFu << sh)) | ((uint32_t)d << sh);
-                        if (d >= near_n) out.far_entries++;
+                        *dw = (*dw & ~(0x3FFu << sh)) | (d << sh);
                     }
-                    out.tiled_entries += (int64_t)(e - b);
                 }
             }
-            // 4. backward index of each slice: its (column, row) pairs sorted by column
+            // 4. backward index of each slice: its (entry value, row) pairs sorted by entry value
             for (int s = 0; s < T.n_slices; s++) {
                 int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
                 pairs.clear();
                 for (int64_t i = a0; i < bnd; i++) {
-                    uint32_t r = perm[(size_t)i];
                     uint32_t in_slice = (uint32_t)(i - a0);
-                    for (uint64_t q = row_ptr[r]; q < row_ptr[r + 1]; q++) pairs.push_back(((uint32_t)loc[(size_t)col_idx[q]] << 16) | in_slice);
+                    for (uint32_t q = rent_ptr[(size_t)(i - i0)]; q < rent_ptr[(size_t)(i - i0) + 1]; q++) pairs.push_back((rent[q] << 16) | in_slice);
                 }
-                ccount.assign((size_t)nd + 1, 0);
+                ccount.assign((size_t)kDictEntries + 1, 0);
                 for (uint32_t p : pairs) ccount[(p >> 16) + 1]++;
-                for (int d = 0; d < nd; d++) ccount[(size_t)d + 1] += ccount[(size_t)d];
+                for (int d = 0; d < kDictEntries; d++) ccount[(size_t)d + 1] += ccount[(size_t)d];
                 sorted.resize(pairs.size());
                 fill.assign(ccount.begin(), ccount.end() - 1);
                 for (uint32_t p : pairs) sorted[fill[p >> 16]++] = p;
                 segs.clear();
                 size_t coo_before = out.coo.size();
-                for (int d = 0; d < nd; d++) {
+                for (int d = 0; d < kDictEntries; d++) {
                     uint32_t b = ccount[(size_t)d], e = ccount[(size_t)d + 1];
                     if (e - b < (uint32_t)dense_min) {
                         for (uint32_t q = b; q < e; q++) out.coo.push_back(((uint32_t)d << 16) | (sorted[q] & 0xFFFF));
@@ -523,8 +571,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 const int m = (int)((nseg + 63) / 64);
                 T.m[s] = (uint16_t)m;
                 size_t base = out.bwd.size();
-                uint32_t empty[4] = {0, 0, 0, 0};                          // unused segment: zero column, padding rows
-                pack10(empty, 0, zero_id);
+                uint32_t empty[4] = {0, 0, 0, 0};                          // unused segment: entry 0 (never flushed), padding rows
                 for (int j = 1; j < 12; j++) pack10(empty, j, pad_row);
                 out.bwd.resize(base + (size_t)m * 64 * 4, 0u);
                 for (int64_t g = 0; g < (int64_t)m * 64; g++) {
@@ -535,6 +582,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                     for (int w = 0; w < 4; w++) out.bwd[u0 + (size_t)w] = src[w];
                 }
             }
+            (void)nd;
             out.tiles.push_back(T);
             for (int32_t t : distinct) stamp[(size_t)t] = -1;
             tile_id++;
@@ -650,13 +698,15 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
                 a.clear();
                 for (int j = 0; j < T.k[s]; j++) {
                     const int fl = i & 63, fi = i >> 6;
-                    int d = (int)((L.fwd[foff + (size_t)j * kSliceDwords + (size_t)(fl * 4 + fi / 3)] >> (10 * (fi % 3))) & 0x3FFu);
-                    if (d > nd) return -4;
-                    if (d == nd) continue;                        // zero slot = padding
-                    a.push_back(tid_of(d));
-                    pf.push_back(((uint32_t)d << 16) | (uint32_t)i);
+                    const uint32_t e = (L.fwd[foff + (size_t)j * kSliceDwords + (size_t)(fl * 4 + fi / 3)] >> (10 * (fi % 3))) & 0x3FFu;
+                    const uint32_t msk = e & (uint32_t)(kBlkEntries - 1);
+                    if (msk == 0) { if (e != 0) return -4; continue; }   // entry 0 = padding
+                    for (int bit = 0; bit < kBlk; bit++)
+                        if (msk >> bit & 1u) a.push_back(tid_of((int)(e >> kBlk) * kBlk + bit));
+                    pf.push_back((e << 16) | (uint32_t)i);
                 }
                 if (r < 0) { if (!a.empty()) return -5; continue; }
+                std::sort(a.begin(), a.end());                    // entries are in block order: the decoded row is compared as a multiset
                 if (L.merged) {                                   // every member row has this tid multiset
                     if (L.mem_ptr[(size_t)r + 1] == L.mem_ptr[(size_t)r]) return -6;
                     for (uint64_t q = L.mem_ptr[(size_t)r]; q < L.mem_ptr[(size_t)r + 1]; q++) {
@@ -672,6 +722,7 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
                 if (seen[(size_t)r]) return -6;
                 seen[(size_t)r] = 1;
                 b.assign(col_idx + row_ptr[r], col_idx + row_ptr[r + 1]);
+                std::sort(b.begin(), b.end());
                 if (a != b) return -7;
             }
             foff += (size_t)T.k[s] * kSliceDwords;
@@ -683,7 +734,7 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
                 for (int w = 1; w < 12; w++) {
                     uint32_t rl = unpack10(q, w);
                     if (rl == (uint32_t)kTileSliceRows) continue;
-                    if (rl > (uint32_t)kTileSliceRows || d >= (uint32_t)nd) return -8;
+                    if (rl > (uint32_t)kTileSliceRows || d >= (uint32_t)kDictEntries || (d & (uint32_t)(kBlkEntries - 1)) == 0) return -8;
                     pb.push_back((d << 16) | rl);
                 }
             }
