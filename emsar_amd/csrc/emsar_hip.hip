@@ -64,6 +64,7 @@ struct emsar_hip_ctx {
     // TILED layout
     emsar::TiledLayout TL;       // host copy keeps slot_row / single_* / left_row (index arrays freed after upload)
     Tile *d_tiles = nullptr;
+    uint32_t *d_units = nullptr; int64_t n_units = 0;     // units of one or two tiles that share a dictionary (k_pass_tiled_unit)
     uint32_t *d_fwd = nullptr, *d_bwd = nullptr;
     uint32_t *d_coo = nullptr;
     int32_t *d_far = nullptr;
@@ -162,6 +163,7 @@ void free_structure(emsar_hip_ctx *ctx) {
     dfree(ctx->d_row_ptr); dfree(ctx->d_col);
     ctx->d_row_ptr = nullptr; ctx->d_col = nullptr;
     dfree(ctx->d_wgt); dfree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
+    dfree(ctx->d_units); ctx->d_units = nullptr; ctx->n_units = 0;
     dfree(ctx->d_tiles); dfree(ctx->d_fwd); dfree(ctx->d_bwd); dfree(ctx->d_coo); dfree(ctx->d_far);
     dfree(ctx->d_left_ptr); dfree(ctx->d_left_col); dfree(ctx->d_left_wgt); dfree(ctx->d_left_val); dfree(ctx->d_u);
     ctx->d_tiles = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_coo = nullptr; ctx->d_far = nullptr;
@@ -196,7 +198,15 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
                 // weights in registers as well the two-tile body does not fit 128 VGPRs (0.218 vs 0.179 ms measured).
                 // Only when the tiles outnumber the chip's workgroup slots: below that a pass is one workgroup's latency, and
                 // a pair takes twice as long as a tile (40 k reads: 47 -> 26 us per pass with one tile per workgroup)
-                if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM);
+                if (ctx->tiled_multi == 1 || ctx->tiled_multi == 5) {         // units: one dictionary for up to two tiles
+#define LAUNCH_U(WT, MD) hipLaunchKernelGGL((k_pass_tiled_unit<WT, MD>), dim3((unsigned)ctx->n_units), block, lds, ctx->stream, ctx->d_tiles, ctx->d_units, \
+                                           ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, theta, acc, ll_out, fx_of(ctx, mode))
+                    if (mode == MODE_EM_LL) LAUNCH_U(false, MODE_EM_LL); else LAUNCH_U(false, MODE_EM);
+#undef LAUNCH_U
+                }
+                else if (ctx->tiled_multi == 3) { if (mode == MODE_EM_LL) LAUNCH_PN(false, MODE_EM_LL, 3); else LAUNCH_PN(false, MODE_EM, 3); }
+                else if (ctx->tiled_multi == 4) { if (mode == MODE_EM_LL) LAUNCH_PN(false, MODE_EM_LL, 4); else LAUNCH_PN(false, MODE_EM, 4); }
+                else if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM);
             }
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
             else { if (mode == MODE_EM_LL) LAUNCH_T(false, MODE_EM_LL); else LAUNCH_T(false, MODE_EM); }
@@ -577,6 +587,8 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
                 return e;
             };
             HIPCHK(up((void **)&ctx->d_tiles, L.tiles.data(), L.tiles.size() * sizeof(Tile)));
+            HIPCHK(up((void **)&ctx->d_units, L.unit_first.data(), L.unit_first.size() * 4));
+            ctx->n_units = L.unit_first.empty() ? 0 : (int64_t)L.unit_first.size() - 1;
             HIPCHK(up((void **)&ctx->d_fwd, L.fwd.data(), L.fwd.size() * 4));
             HIPCHK(up((void **)&ctx->d_bwd, L.bwd.data(), L.bwd.size() * 4));
             HIPCHK(up((void **)&ctx->d_coo, L.coo.data(), L.coo.size() * 4));
@@ -596,6 +608,10 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
 #undef SETLDS_T
 #define SETLDS_P(WT, MD, NN) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_multi<WT, MD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             SETLDS_P(false, MODE_EM, 2); SETLDS_P(false, MODE_EM_LL, 2);
+#define SETLDS_U(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_unit<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+            SETLDS_U(false, MODE_EM); SETLDS_U(false, MODE_EM_LL);
+#undef SETLDS_U
+            SETLDS_P(false, MODE_EM, 3); SETLDS_P(false, MODE_EM_LL, 3); SETLDS_P(false, MODE_EM, 4); SETLDS_P(false, MODE_EM_LL, 4);
 #undef SETLDS_P
             { const char *pe = getenv("EMSAR_HIP_TILED_MULTI"); ctx->tiled_multi = pe ? atoi(pe) : 1; }
             { const char *pe = getenv("EMSAR_HIP_UPDATE_GRID"); if (pe && atoi(pe) >= 1) ctx->update_grid = atoi(pe); }

@@ -504,6 +504,57 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Til
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_pass_tiled_unit: one workgroup per UNIT -- one or two tiles that share a dictionary (the second `follows` the first:
+// layout_tiled.hpp).  With block entries a slice is half the work it was, and the per-tile chain (dictionary fetch -> table ->
+// barrier ... barrier -> flush) had grown to 44 % of a wave's life in barrier waits: a unit pays it once for up to eight slices.
+// Tile 2's forward columns are requested while tile 1's M-step runs, its backward segments afterwards (as in k_pass_tiled_multi).
+// ------------------------------------------------------------------------------------------------
+template <bool WEIGHTED, int MODE>
+__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile *__restrict__ tiles, const uint32_t *__restrict__ unit_first,
+                                                                   const uint32_t *__restrict__ fwd, const uint32_t *__restrict__ bwd,
+                                                                   const uint32_t *__restrict__ coo, const int32_t *__restrict__ far_tid,
+                                                                   const int32_t *__restrict__ wgt, const double *__restrict__ theta,
+                                                                   double *__restrict__ acc, double *__restrict__ ll_out, Fx fx) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double red[kTiledThreads / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *th_w = lds, *acc_w = lds + kTiledDictPad, *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;
+    const uint32_t t0 = unit_first[blockIdx.x], t1 = unit_first[blockIdx.x + 1];
+    const Tile T = tiles[t0];
+    const bool two = t1 - t0 > 1;
+    const Tile T2 = tiles[two ? t0 + 1 : t0];
+    const TileWave W = tile_wave(T, wave, lane, fwd, bwd);
+    BlockDict D;
+    int4 A[8], B[8];
+    block_dict_issue<MODE>(T, W.nd, far_tid, theta, D);
+    if (W.has_slice) {
+        load8_clamped(A, W.e, W.k < 8 ? W.k : 8);
+        if (W.m > 0) load8_clamped(B, W.b, W.m < 8 ? W.m : 8);
+    }
+    if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;
+    block_dict_store(D, th_w, acc_w);
+    __syncthreads();
+    double ll = 0.0;
+    if (W.has_slice) tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)wave * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
+    TileWave W2 = tile_wave(T2, wave, lane, fwd, bwd);
+    if (!two) W2.has_slice = false;
+    if (W2.has_slice) load8_clamped(A, W2.e, W2.k < 8 ? W2.k : 8);
+    if (W.has_slice) tile_m_step(W, B, coo, w_s, acc_w, lane, fx.mass);
+    if (W2.has_slice) {
+        if (W2.m > 0) load8_clamped(B, W2.b, W2.m < 8 ? W2.m : 8);
+        tile_e_step<WEIGHTED, MODE>(W2, A, (size_t)T2.row_base + (size_t)wave * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
+        tile_m_step(W2, B, coo, w_s, acc_w, lane, fx.mass);
+    }
+    __syncthreads();
+    block_dict_flush(D, th_w, acc_w, acc, fx.mass);
+    if (MODE == MODE_EM_LL) {
+        double t = block_sum<kTiledThreads>(ll, red);
+        if (threadIdx.x == 0 && t != 0.0) ll_add(ll_out, t, fx.ll);
+    }
+}
+
 // likelihood terms of the folded single-tid rows: sum_t u_t log theta_t
 __global__ __launch_bounds__(256) void k_single_ll(int n, const double *__restrict__ u, const double *__restrict__ theta, double *ll_out, double fx_ll) {
     __shared__ double red[4];

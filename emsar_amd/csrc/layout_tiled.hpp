@@ -57,7 +57,8 @@ constexpr int kDictBlocks = 120;
 constexpr int kDictEntries = kDictBlocks * kBlkEntries;   // 960 doubles of LDS for T, 960 for the per-entry accumulators
 constexpr int kTileDict = kBlk * kDictBlocks;    // 360 transcripts per tile
 constexpr int64_t kFragRows = 1 << 21;   // sorted rows per independently tiled fragment (build_tiled)
-constexpr int kMaxRowLen = kTileDict;  // longer rows -> leftover CSR (a row must fit one dictionary)
+constexpr int kTileTids = kTileDict - (kBlk - 1);   // distinct transcripts of a tile: its near range starts at a multiple of kBlk, which may cost kBlk - 1 slots
+constexpr int kMaxRowLen = kTileTids;  // longer rows -> leftover CSR (a row must fit one dictionary)
 constexpr int kSegRows = 11;           // row ids per backward segment (plus 1 header = 12 x 10 bit = one int4)
 constexpr int kSliceDwords = kTileSliceRows / 3;    // dwords per forward column of a slice (256 = 1 KiB)
 
@@ -105,7 +106,7 @@ struct Tile {                // 64 bytes
     int32_t lo;              // dictionary slot d < near_n  <->  tid lo + d
     uint16_t near_n, far_n;  // slot near_n + i <-> far_tid[far_off + i]; zero slot = near_n + far_n
     uint16_t n_slices;       // <= 4
-    uint16_t pad0;
+    uint16_t follows;        // 1: this tile uses the dictionary of the tile before it (second half of a unit of up to 8 slices)
     uint16_t k[4];           // padded row length of each slice's forward index
     uint16_t m[4];           // backward segments (int4) per lane of each slice
     uint16_t coo_n[4];       // COO pairs of each slice
@@ -120,6 +121,7 @@ struct TiledLayout {
     std::vector<int32_t> single_tid;
     // tiles
     std::vector<Tile> tiles;
+    std::vector<uint32_t> unit_first;   // n_units + 1: the tiles of unit u are unit_first[u] .. unit_first[u+1] (one or two; the second follows)
     i64_vec slot_row;                   // row slot -> original row, or merged-row id when `merged` (-1 = padding)
     bool merged = false;                // identical rows were merged: a slot stands for mem_row[mem_ptr[id] .. mem_ptr[id+1])
     std::vector<uint64_t> mem_ptr;
@@ -203,6 +205,21 @@ inline int check_tiled_extents(const TiledLayout &L) {
                 if (!entry_ok(p >> 16) || ((p >> 16) & (uint32_t)(kBlkEntries - 1)) == 0 || (p & 0xFFFFu) >= (uint32_t)kTileSliceRows) return -29;
             }
             foff += fw; boff += bw; coff += T.coo_n[s];
+        }
+    }
+    for (size_t i = 0; i < L.tiles.size(); i++) {            // a tile that follows shares the dictionary of the tile before it
+        const Tile &T = L.tiles[i];
+        if (T.follows > 1 || (T.follows && i == 0)) return -30;
+        if (T.follows) {
+            const Tile &P = L.tiles[i - 1];
+            if (P.follows || P.lo != T.lo || P.near_n != T.near_n || P.far_n != T.far_n || P.far_off != T.far_off) return -30;
+        }
+    }
+    if (!L.tiles.empty()) {
+        if (L.unit_first.size() < 2 || L.unit_first.front() != 0 || L.unit_first.back() != L.tiles.size()) return -31;
+        for (size_t u = 0; u + 1 < L.unit_first.size(); u++) {
+            const uint32_t a = L.unit_first[u], b = L.unit_first[u + 1];
+            if (b <= a || b - a > 2 || b > L.tiles.size() || L.tiles[a].follows || (b - a == 2 && !L.tiles[a + 1].follows)) return -31;
         }
     }
     for (int64_t r : L.slot_row) if (r < -1 || r >= (L.merged ? (int64_t)L.mem_ptr.size() - 1 : L.n_rows)) return -20;
@@ -304,6 +321,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         return nt;
     };
     std::vector<int32_t> mintid((size_t)n_rows, -1);      // the anchor tid of every tiled row (see below)
+    std::vector<uint16_t> ecnt((size_t)n_rows, 0);        // its number of block entries (dictionaries start at multiples of kBlk, so
+                                                          // a near tid t lies in block t / kBlk whatever the tile): the sort's length
     bool anchor_median = true;
     if (const char *e = getenv("EMSAR_HIP_TILE_ANCHOR")) anchor_median = atoi(e) != 0;
     // the row's anchor in tid space decides which tile it joins: the MEDIAN id, not the smallest -- a read that also
@@ -315,16 +334,17 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         for (int64_t r = lo; r < hi; r++) {
             const uint64_t b = row_ptr[r], e = row_ptr[r + 1], len = e - b;
             if (len < 2 || len > (uint64_t)kMaxRowLen) continue;
-            int32_t m;
-            if (anchor_median) {
-                tmp.assign(col_idx + b, col_idx + e);
-                std::nth_element(tmp.begin(), tmp.begin() + (std::ptrdiff_t)(len / 2), tmp.end());
-                m = tmp[(size_t)(len / 2)];
-            } else {
-                m = col_idx[b];
-                for (uint64_t k = b + 1; k < e; k++) m = std::min(m, col_idx[k]);
+            tmp.assign(col_idx + b, col_idx + e);
+            std::sort(tmp.begin(), tmp.end());
+            mintid[(size_t)r] = anchor_median ? tmp[(size_t)(len / 2)] : tmp[0];
+            int n_ent = 0, cur_b = -1;
+            uint32_t cur_m = 0;
+            for (int32_t t : tmp) {                        // the rule of slots_to_entries, on tids
+                const int bb = t / kBlk;
+                const uint32_t bit = 1u << (t % kBlk);
+                if (bb != cur_b || (cur_m & bit)) { n_ent++; cur_b = bb; cur_m = bit; } else cur_m |= bit;
             }
-            mintid[(size_t)r] = m;
+            ecnt[(size_t)r] = (uint16_t)n_ent;
         }
     });
     std::vector<uint32_t> act;                             // the tiled rows, ascending
@@ -365,10 +385,13 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     const int64_t n_act = (int64_t)act.size();
     // Sort granularity in tid space.  A tile's dictionary must hold a block's tid range plus the rows' reach, so
     // blocks stay small; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
-    int32_t block = 96;        // the rows of one block of the sort fit one dictionary (360 transcripts) with room for their far hits;
-                               // config 3: 256 / 192 / 160 / 128 / 96 tids -> 0.145 / 0.139 / 0.136 / 0.134 / 0.124 ms per pass
+    int32_t block = 128;       // the rows of one block of the sort fit one dictionary (360 transcripts) with room for their far hits;
+                               // config 3, rows sorted by entry count inside a block: 96 / 128 / 160 / 192 tids -> 0.1178 / 0.1169 / 0.1187 / 0.124 ms per pass
     if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 900) block = v; }
     int64_t tile_rows = kTileRows;
+    int unit_tiles = 2;                 // tiles that may share one dictionary (a unit: one workgroup, one dictionary load, one flush)
+    if (const char *e = getenv("EMSAR_HIP_UNIT_TILES")) { int v = atoi(e); if (v >= 1 && v <= 2) unit_tiles = v; }
+    const int64_t unit_rows = tile_rows * unit_tiles;
     if (const char *e = getenv("EMSAR_HIP_TILE_ROWS")) { int v = atoi(e); if (v >= kTileSliceRows && v <= kTileRows) tile_rows = v / kTileSliceRows * kTileSliceRows; }
     int dense_min = kDenseMin;
     if (const char *e = getenv("EMSAR_HIP_TILE_DENSE")) { int v = atoi(e); if (v >= 1 && v <= 64) dense_min = v; }
@@ -406,7 +429,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         std::vector<uint32_t>().swap(act);
         const int64_t n_blocks = ((int64_t)n_tx + block - 1) / block;
         counting_sort(pa, perm, (size_t)(n_blocks * kLenClasses), [&](uint32_t r) {
-            return (size_t)(mintid[r] / block) * kLenClasses + (size_t)len_class((int64_t)(row_ptr[r + 1] - row_ptr[r]));
+            return (size_t)(mintid[r] / block) * kLenClasses + (size_t)len_class((int64_t)ecnt[r]);
         });
     }
     std::vector<uint32_t>().swap(pa);
@@ -430,16 +453,16 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             // 1. how many rows fit: row cap, entry cap, distinct-tid cap
             distinct.clear();
             int64_t ents = 0, i1 = i0;
-            while (i1 < n_act && i1 - i0 < tile_rows) {
+            while (i1 < n_act && i1 - i0 < unit_rows) {
                 uint32_t r = perm[(size_t)i1];
                 uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-                if (i1 > i0 && ents + (int64_t)(e - b) > kTileEntries) break;
+                if (i1 > i0 && ents + (int64_t)(e - b) > 2 * kTileEntries) break;
                 size_t before = distinct.size();
                 for (uint64_t k = b; k < e; k++) {
                     int32_t t = col_idx[k];
                     if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
                 }
-                if (i1 > i0 && (int64_t)distinct.size() > kTileDict) {   // undo this row, close the tile
+                if (i1 > i0 && (int64_t)distinct.size() > kTileTids) {   // undo this row, close the tile
                     for (size_t q = before; q < distinct.size(); q++) stamp[(size_t)distinct[q]] = -1;
                     distinct.resize(before);
                     break;
@@ -447,7 +470,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 ents += (int64_t)(e - b);
                 i1++;
             }
-            if ((int64_t)distinct.size() > kTileDict) return -3;       // a single row with too many tids: excluded by kMaxRowLen
+            if ((int64_t)distinct.size() > kTileTids) return -3;       // a single row with too many tids: excluded by kMaxRowLen
             // a tile closed by the dictionary or entry cap in the middle of a slice would pad that slice with empty rows
             // (forward bytes and gathers for nothing): give the rows of the started slice to the next tile instead
             if (cut_at_slices && i1 < n_act && i1 - i0 > kTileSliceRows && (i1 - i0) % kTileSliceRows != 0) {
@@ -470,31 +493,25 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             const size_t n = distinct.size();
             size_t best_a = 0, best_c = 0, a = 0;
             for (size_t c = 0; c < n; c++) {
-                while ((int64_t)n + ((int64_t)distinct[c] - distinct[a]) - (int64_t)(c - a) > kTileDict) a++;
+                while ((int64_t)n + ((int64_t)distinct[c] - distinct[a]) - (int64_t)(c - a) + (kBlk - 1) > kTileDict) a++;
                 if (c == 0 || c - a > best_c - best_a) { best_a = a; best_c = c; }
             }
-            const int32_t lo = distinct[best_a];
+            const int32_t lo = distinct[best_a] - distinct[best_a] % kBlk;       // blocks of the near range = tid / kBlk (see ecnt)
             const int32_t near_n = distinct[best_c] - lo + 1;
-            const int32_t far_n = (int32_t)(n - (best_c - best_a + 1));
             Tile T;
             std::memset(&T, 0, sizeof T);
-            T.lo = lo; T.near_n = (uint16_t)near_n; T.far_n = (uint16_t)far_n;
+            T.lo = lo; T.near_n = (uint16_t)near_n;
             T.far_off = (uint32_t)out.far_tid.size();
             for (size_t q = 0; q < distinct.size(); q++) {
                 int32_t t = distinct[q];
                 if (t >= lo && t - lo < near_n) loc[(size_t)t] = t - lo;
                 else { loc[(size_t)t] = near_n + (int32_t)(out.far_tid.size() - T.far_off); out.far_tid.push_back(t); }
             }
+            const int32_t far_n = (int32_t)(out.far_tid.size() - T.far_off);     // (rounding lo down may have taken in a tid or two)
+            T.far_n = (uint16_t)far_n;
             const int nd = near_n + far_n;
             const uint32_t pad_row = (uint32_t)kTileSliceRows;             // w_r[768] of every slice = 0
-            const int64_t nrow = i1 - i0;
-            T.n_slices = (uint16_t)((nrow + kTileSliceRows - 1) / kTileSliceRows);
-            T.row_base = (uint32_t)out.slot_row.size();
-            out.slot_row.resize(out.slot_row.size() + (size_t)T.n_slices * kTileSliceRows, -1);
-            T.fwd_off = (uint64_t)out.fwd.size() * 4;
-            T.bwd_off = (uint64_t)out.bwd.size() * 4;
-            T.coo_off = (uint32_t)out.coo.size();
-            out.n_fslices += T.n_slices;
+            const Tile Tdict = T;                                          // what the tiles of the unit share: the dictionary
             // the entries of every row of the tile, once (used by the forward and by the backward index)
             rent_ptr.assign(1, 0u); rent.clear();
             for (int64_t i = i0; i < i1; i++) {
@@ -510,12 +527,24 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 rent_ptr.push_back((uint32_t)rent.size());
                 out.tiled_entries += (int64_t)rents.size();
             }
+            // the rows of the unit go to its tiles in order, up to tile_rows each; the second tile `follows` the first
+            for (int64_t pa0 = i0; pa0 < i1; pa0 += tile_rows) {
+            const int64_t pa1 = std::min(i1, pa0 + tile_rows);
+            T = Tdict;
+            T.follows = pa0 > i0 ? 1 : 0;
+            T.n_slices = (uint16_t)((pa1 - pa0 + kTileSliceRows - 1) / kTileSliceRows);
+            T.row_base = (uint32_t)out.slot_row.size();
+            out.slot_row.resize(out.slot_row.size() + (size_t)T.n_slices * kTileSliceRows, -1);
+            T.fwd_off = (uint64_t)out.fwd.size() * 4;
+            T.bwd_off = (uint64_t)out.bwd.size() * 4;
+            T.coo_off = (uint32_t)out.coo.size();
+            out.n_fslices += T.n_slices;
             // 3. forward slices (all of them first: the tile's forward block is contiguous).  Column j of a slice is 256
             //    dwords; row p of the slice (p = position in sorted order) is field p/64 of the int4 of lane p%64: the 64
             //    lanes of one E-step gather read 64 CONSECUTIVE sorted rows, i.e. mostly one family -- the same few
             //    table entries (LDS broadcast) or neighbouring ones (distinct banks) instead of a random spread
             for (int s = 0; s < T.n_slices; s++) {
-                int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
+                int64_t a0 = pa0 + (int64_t)s * kTileSliceRows, bnd = std::min(pa1, a0 + kTileSliceRows);
                 int64_t k = 0;
                 for (int64_t i = a0; i < bnd; i++) k = std::max<int64_t>(k, (int64_t)(rent_ptr[(size_t)(i - i0) + 1] - rent_ptr[(size_t)(i - i0)]));
                 T.k[s] = (uint16_t)k;
@@ -538,7 +567,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             }
             // 4. backward index of each slice: its (entry value, row) pairs sorted by entry value
             for (int s = 0; s < T.n_slices; s++) {
-                int64_t a0 = i0 + (int64_t)s * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
+                int64_t a0 = pa0 + (int64_t)s * kTileSliceRows, bnd = std::min(pa1, a0 + kTileSliceRows);
                 pairs.clear();
                 for (int64_t i = a0; i < bnd; i++) {
                     uint32_t in_slice = (uint32_t)(i - a0);
@@ -584,6 +613,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             }
             (void)nd;
             out.tiles.push_back(T);
+            }
             for (int32_t t : distinct) stamp[(size_t)t] = -1;
             tile_id++;
             i0 = i1;
@@ -660,7 +690,24 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         for (int s = 0; s < t.n_slices; s++) w += (int64_t)t.k[s] * kTileSliceRows + (int64_t)t.m[s] * 64 * 12 + t.coo_n[s] * 2;
         return w;
     };
-    std::stable_sort(out.tiles.begin(), out.tiles.end(), [&](const Tile &a, const Tile &b) { return work(a) > work(b); });
+    {   // the sort moves whole units (a tile and the one that follows it)
+        struct Unit { uint32_t first, n; int64_t w; };
+        std::vector<Unit> units;
+        for (size_t i = 0; i < out.tiles.size(); i++) {
+            if (out.tiles[i].follows && !units.empty()) { units.back().n++; units.back().w += work(out.tiles[i]); }
+            else { out.tiles[i].follows = 0; units.push_back(Unit{(uint32_t)i, 1u, work(out.tiles[i])}); }
+        }
+        std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.w > b.w; });
+        std::vector<Tile> sorted_tiles;
+        sorted_tiles.reserve(out.tiles.size());
+        out.unit_first.clear();
+        for (const Unit &u : units) {
+            out.unit_first.push_back((uint32_t)sorted_tiles.size());
+            for (uint32_t j = 0; j < u.n; j++) sorted_tiles.push_back(out.tiles[u.first + j]);
+        }
+        out.unit_first.push_back((uint32_t)sorted_tiles.size());
+        out.tiles.swap(sorted_tiles);
+    }
     if (dbg_t) fprintf(stderr, "build_tiled: total %.0f ms\n", t_ms(tp0, t_now()));
     const int ext = check_tiled_extents(out);       // nothing reaches the device unless every descriptor stays inside its arrays
     return ext == 0 ? 0 : ext;
