@@ -9,8 +9,8 @@ N>1 (torchrun, one rank per GPU): the -M multi-sample path -- every rank solves 
 of the same shape (different seed), no data-path collective; weak scaling.  The only torch.distributed use
 is the barrier and the max-over-ranks of the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the TILED layout, k_pass_tiled /
-k_pass_tiled_multi<2> (+ the small k_update that shares the pass): algorithmic bytes per pass /
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the TILED layout, k_pass_tiled_unit
+(+ the small k_update that shares the pass): algorithmic bytes per pass /
 mean device time per pass measured with HIP events on the library's own stream (`frac_actual`: the same with the HBM bytes the PMC
 counters saw, profiles/traffic.json).  After the timed passes: `solve_to_convergence` (the same matrix solved to --solve) and
 `fpkm_delta_vs_oracle` (a down-scaled config 3 solved by both).  `cpu_baseline` times the CPU oracle's OpenMP EM pass on the same
@@ -124,7 +124,7 @@ def main():
     out = None
     if rank == 0:
         per_pass_s = kernel_ms / 1e3 / args.steps
-        tiled_kernel = "k_pass_tiled"
+        tiled_kernel = "k_pass_tiled_unit"      # above 2048 tiles (below: k_pass_tiled, one tile per workgroup)
         bytes_pass = info["bytes_per_pass"]
         achieved = bytes_pass / per_pass_s / 1e9
         out = {
@@ -136,8 +136,9 @@ def main():
                        "layout": {1: "csr", 3: "tiled", 259: "tiled+merged-rows"}[info["layout"]], "parallelism": "1 sample per GPU x %d" % world},
             "read_alignments_per_s": world * nnz * args.steps / wall,
             # achieved / frac: ALGORITHMIC bytes (SURVEY.md 8d formula, what a CSR walk would stream) per second -- the TILED layout stores
-            # and moves far fewer bytes (stored_bytes_per_pass, traffic), so frac may exceed what real traffic / time gives:
-            # hbm_actual_GBps / frac_actual below are the measured-traffic figures
+            # and moves a third of them (stored_bytes_per_pass, traffic), so `achieved` exceeds the HBM peak and frac exceeds 1: the
+            # kernel is NOT running above the roofline, it reads fewer bytes than the formula counts.  hbm_actual_GBps / frac_actual
+            # below are the measured-traffic figures (what the HBM really delivered)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": {1: "k_pass_csr", 3: tiled_kernel, 259: "k_pass_tiled"}[info["layout"]] + "+k_update",

@@ -42,7 +42,7 @@ def test_passes_agree_across_kernels_to_the_fixed_point_resolution(monkeypatch):
     small multiple of the grid, N * 2^-61 reads; within one kernel the bits are the same (test above)."""
     s = synth.make_config("cfg3", 0.004)
     out = {}
-    for name, layout, multi in (("tiled1", LAYOUT_TILED, "0"), ("tiled2", LAYOUT_TILED, "2"), ("csr", LAYOUT_CSR, "0")):
+    for name, layout, multi in (("tiled1", LAYOUT_TILED, "0"), ("tiled2", LAYOUT_TILED, "2"), ("unit", LAYOUT_TILED, "5"), ("csr", LAYOUT_CSR, "0")):
         monkeypatch.setenv("EMSAR_HIP_TILED_MULTI", multi)
         with EmsarHip(0) as ctx:
             ctx.set_deterministic(True)
@@ -53,7 +53,7 @@ def test_passes_agree_across_kernels_to_the_fixed_point_resolution(monkeypatch):
     # every contribution is rounded to the grid once (N * 2^-61 reads = 8.7e-14 here): a transcript with k contributions is within
     # k / 2 grid steps of the exact sum, and the CSR kernel makes one contribution per row where the tile kernel makes one per 11
     res = s["n_reads"] * 2.0 ** -61 * 20000
-    for other in ("tiled2", "csr"):
+    for other in ("tiled2", "unit", "csr"):
         assert np.all(np.abs(out["tiled1"][0] - out[other][0]) * s["den"] <= res + 1e-11 * out[other][0] * s["den"]), other
         assert abs(out["tiled1"][1] - out[other][1]) <= 1e-11 * abs(out[other][1])
 

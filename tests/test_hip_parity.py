@@ -312,7 +312,7 @@ def test_full_size_properties_cfg5(dev):
     _full_size_properties(dev, s, passes=2, csr_passes=2)
 
 
-@pytest.mark.parametrize("multi", ["0", "2"])
+@pytest.mark.parametrize("multi", ["0", "2", "5"])
 def test_loglik_of_unweighted_rows_at_extreme_theta(monkeypatch, multi):
     """The unweighted TILED kernels take the log of a product of six row sums instead of six logs; a product that
     leaves the double range falls back to the per-row logs.  theta of 1e-70 / 1e+70 everywhere (products 1e-420 / 1e+420),
@@ -336,8 +336,9 @@ def test_loglik_of_unweighted_rows_at_extreme_theta(monkeypatch, multi):
 
 
 def test_tiled_pair_and_single_kernels_match_oracle(monkeypatch):
-    """Unweighted TILED passes run two tiles per workgroup (k_pass_tiled_multi) only when the tiles outnumber the chip's
-    workgroup slots, one (k_pass_tiled) below that; the knob forces either kernel on a matrix of a few dozen tiles.  The
+    """Unweighted TILED passes run a unit of up to two tiles per workgroup (k_pass_tiled_unit) only when the tiles outnumber the
+    chip's workgroup slots, one tile (k_pass_tiled) below that; the knob forces either kernel, or the two-independent-tiles
+    kernel (k_pass_tiled_multi), on a matrix of a few dozen tiles.  The
     solve is long enough for the hipGraph replay of the SQUAREM cycle to start (4 x check_every cycles in)."""
     s = synth.make_config("cfg3", 0.004)
     m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
@@ -345,7 +346,7 @@ def test_tiled_pair_and_single_kernels_match_oracle(monkeypatch):
     for _ in range(3):
         want, _ = m.em_step(want, s["den"], n_threads=4)
     F = {}
-    for multi, graph in (("0", "1"), ("2", "1"), ("2", "0")):
+    for multi, graph in (("0", "1"), ("2", "1"), ("2", "0"), ("5", "1")):       # one tile / two tiles / a unit (shared dictionary) per workgroup
         monkeypatch.setenv("EMSAR_HIP_TILED_MULTI", multi)
         monkeypatch.setenv("EMSAR_HIP_GRAPH", graph)
         with EmsarHip(0) as ctx:
