@@ -126,36 +126,50 @@ __device__ __forceinline__ void block_dict_issue(const Tile &T, int nd, const in
     }
 }
 __device__ __forceinline__ void block_dict_store(const BlockDict &D, double *th_w, double *acc_w) {
+    constexpr int NE = emsar::kBlkEntries;
     if (threadIdx.x < emsar::kDictBlocks) {
-        double *t = th_w + threadIdx.x * 8, *a = acc_w + threadIdx.x * 8;
-        const double x0 = D.th[0], x1 = D.th[1], x2 = D.th[2];
-        t[0] = 0.0; t[1] = x0; t[2] = x1; t[3] = x0 + x1; t[4] = x2; t[5] = x0 + x2; t[6] = x1 + x2; t[7] = (x0 + x1) + x2;
+        double *t = th_w + threadIdx.x * NE, *a = acc_w + threadIdx.x * NE;
+        double v[NE];
+        v[0] = 0.0;
 #pragma unroll
-        for (int m = 0; m < 8; m++) a[m] = 0.0;
+        for (int m = 1; m < NE; m++) {                 // subset sum of m = that of m without its highest slot + theta of that slot
+            const int hi = 31 - __builtin_clz((unsigned)m);
+            v[m] = v[m & ~(1 << hi)] + D.th[hi];
+        }
+#pragma unroll
+        for (int m = 0; m < NE; m++) { t[m] = v[m]; a[m] = 0.0; }
     }
 }
 __device__ __forceinline__ void block_dict_flush(const BlockDict &D, const double *th_w, const double *acc_w, double *acc, double fx) {
+    constexpr int NE = emsar::kBlkEntries;
     if (threadIdx.x >= emsar::kDictBlocks || D.tid[0] < 0) return;
-    const double *a = acc_w + threadIdx.x * 8;
+    const double *a = acc_w + threadIdx.x * NE;
+    double c[NE];
     if (fx != 0.0) {
         // deterministic mode: W[e] holds, as an integer, the MASS of entry e (sum of w_r T[e] fx over its rows: tile_acc_add);
         // the column sum of the entry is that over T[e], transcript i gets theta_i times the sum over the subsets that hold it
-        const double *t = th_w + threadIdx.x * 8;
-        double c[8];
+        const double *t = th_w + threadIdx.x * NE;
 #pragma unroll
-        for (int m = 1; m < 8; m++) { const double tm = t[m]; c[m] = tm > 0.0 ? (double)__double_as_longlong(a[m]) / tm : 0.0; }
-        const double s[kBlk] = {(c[1] + c[3]) + (c[5] + c[7]), (c[2] + c[3]) + (c[6] + c[7]), (c[4] + c[5]) + (c[6] + c[7])};
+        for (int m = 1; m < NE; m++) { const double tm = t[m]; c[m] = tm > 0.0 ? (double)__double_as_longlong(a[m]) / tm : 0.0; }
 #pragma unroll
         for (int i = 0; i < kBlk; i++) {
             if (D.tid[i] < 0) continue;
-            const long long iv = __double2ll_rn(t[1 << i] * s[i]);
+            double si = 0.0;
+#pragma unroll
+            for (int m = 1; m < NE; m++) if (m >> i & 1) si += c[m];
+            const long long iv = __double2ll_rn(t[1 << i] * si);
             if (iv != 0) atomic_add_i64(&acc[D.tid[i]], iv);
         }
     } else {
-        const double s[kBlk] = {(a[1] + a[3]) + (a[5] + a[7]), (a[2] + a[3]) + (a[6] + a[7]), (a[4] + a[5]) + (a[6] + a[7])};
 #pragma unroll
-        for (int i = 0; i < kBlk; i++)
-            if (D.tid[i] >= 0 && s[i] != 0.0) atomic_add_f64(&acc[D.tid[i]], s[i]);
+        for (int m = 1; m < NE; m++) c[m] = a[m];
+#pragma unroll
+        for (int i = 0; i < kBlk; i++) {
+            double si = 0.0;
+#pragma unroll
+            for (int m = 1; m < NE; m++) if (m >> i & 1) si += c[m];
+            if (D.tid[i] >= 0 && si != 0.0) atomic_add_f64(&acc[D.tid[i]], si);
+        }
     }
 }
 
