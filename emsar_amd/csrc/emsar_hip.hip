@@ -879,8 +879,12 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
     ctx->delta_mask = nullptr;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (use_sets) {
-        SetSolveParams P{p.tol, p.abs_floor, p.count_floor, p.zero_cut > 0.0 ? p.zero_cut : 0.0, p.abs_step > 0.0 ? p.abs_step : 0.0, p.max_iter, p.accel,
-                         p.newton_after == 0 ? 60 : p.newton_after};
+        // zero_cut / abs_step exist because a boundary optimum is approached like 1/k by the EM; the sets that get Newton steps reach it
+        // in a few steps and are held to the strict rule (same pass counts with and without the two rules on every problem measured,
+        // and then nothing is printed differently); the rules stay in force for the streamed part and with newton_after < 0
+        const bool strict_sets = p.newton_after >= 0;
+        SetSolveParams P{p.tol, p.abs_floor, p.count_floor, (!strict_sets && p.zero_cut > 0.0) ? p.zero_cut : 0.0,
+                         (!strict_sets && p.abs_step > 0.0) ? p.abs_step : 0.0, p.max_iter, p.accel, p.newton_after == 0 ? 60 : p.newton_after};
         if ((rc = solve_resident_sets(ctx, P, th[0]))) return rc;
         if (ctx->n_sstat > 0)
             HIPCHK(hipMemcpyAsync(ctx->h_sstat, ctx->d_sstat, (size_t)ctx->n_sstat * sizeof(SetStat), hipMemcpyDeviceToHost, ctx->stream));

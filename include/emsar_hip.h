@@ -81,6 +81,8 @@ typedef struct {
                              pass K is at most ~a*K, so the rule bounds the remaining drift by abs_step * 2e5 at every K --
                              2e-8 FPKM, a fiftieth of the .fpkm print quantum, for 1e-13 -- while the relative rule at 1e-10
                              keeps such components going for 10^5 passes.  <= 0 = off. */
+    /* (zero_cut and abs_step apply to the streaming passes, and to the resident sets only when newton_after < 0: a set that gets
+       Newton steps reaches a boundary optimum in a few of them and is held to the strict rule) */
     int32_t newton_after; /* set_mode 0, resident sets: a set that has not converged after this many passes gets one safeguarded
                              projected-Newton step (direction by matrix-free conjugate gradients, accepted only if F does not
                              fall) after every SQUAREM cycle.  0 -> 60, < 0 = never (EM / SQUAREM only). */
