@@ -1,4 +1,4 @@
-// kernels_tiled.hpp -- k_pass_tiled / k_pass_tiled_multi: the EM pass over the TILED layout (layout_tiled.hpp), the default
+// kernels_tiled.hpp -- k_pass_tiled / k_pass_tiled_unit / k_pass_tiled_multi: the EM pass over the TILED layout (layout_tiled.hpp), the default
 #pragma once
 // included by emsar_hip.hip only (one translation unit: the kernels live in its anonymous namespace)
 
@@ -6,14 +6,18 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // k_pass_tiled: one EM pass over the TILED layout (layout_tiled.hpp).  One workgroup = 4 waves = the 4 slices of a tile.
-//   phase 0  every global load the wave needs first is issued at once (dictionary theta values, 8 forward columns,
-//            8 backward segments); dictionary: th_w[d] = theta[tid(d)], acc_w[d] = 0, zero slots; barrier
-//   phase E  the wave owns one slice (768 rows; lane l holds rows 64*i + l, i < 12): S_r = sum th_w[id]  (LDS reads only, 10-bit ids,
-//            padding reads the zero slot: no branches), w_r = R_r / S_r -> the wave's own 6 KiB of LDS
-//   phase M  the SAME wave walks the transposed index of its rows: a lane's segments (column id + 11 row ids) are
-//            consecutive in column order; it gathers w_r from LDS into a register sum and adds it to acc_w when the
-//            column changes; tiny columns via a COO list.  No barrier between E and M.
-//   phase F  barrier; non-zero dictionary slots are flushed with one global FP64 atomic each
+//   phase 0  every global load the wave needs first is issued at once (the three theta of the thread's dictionary block, 8
+//            forward columns, 8 backward segments); table: T[8b + m] = sum of the theta of block b's slots in subset m, the
+//            per-entry accumulators W[8b + m] = 0; barrier
+//   phase E  the wave owns one slice (768 rows; lane l holds rows 64*i + l, i < 12): S_r = sum T[entry]  (LDS reads only, 10-bit
+//            entries = block and subset, padding is entry 0 = the empty subset: no branches), w_r = R_r / S_r -> the wave's own
+//            6 KiB of LDS
+//   phase M  the SAME wave walks the transposed index of its rows: a lane's segments (entry value + 11 row ids) are
+//            consecutive in entry order; it gathers w_r from LDS into a register sum and adds it to W[entry] when the
+//            entry changes.  No barrier between E and M.
+//   phase F  barrier; thread b folds the 8 accumulators of block b into its 3 transcripts (transcript i collects the subsets
+//            that hold it) and flushes them with one global FP64 atomic each
+// k_pass_tiled_unit (the default above 2048 tiles): the same for a UNIT of up to two tiles that share one dictionary.
 // HBM traffic: 10 bits per forward slot + 128 bits per 11 backward entries -- no row_ptr, no 32-bit tids.
 // ------------------------------------------------------------------------------------------------
 constexpr int kTiledThreads = 256;                       // 4 wavefronts = 4 slices

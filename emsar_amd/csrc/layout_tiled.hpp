@@ -5,18 +5,19 @@
 //
 //   * rows with ONE tid never reach the kernel: they are folded into a per-transcript count vector u
 //     (acc_t += u_t / theta_t is applied analytically in k_update);
-//   * rows with 2..kMaxRowLen tids are sorted by (block(anchor tid), length class, anchor tid), anchor = median tid, like the WINDOWED
-//     layout and cut into TILES of at most 3072 rows whose distinct tids fit a 959-entry chunk-local
-//     DICTIONARY: the contiguous range [lo, lo+near_n) that covers most of the tile's tids plus an explicit list
-//     of far tids.  Every stored operand is a 10-BIT id (dictionary slot < 1024, slice row < 1024), three to a dword;
-//   * a tile has up to 4 SLICES of 768 rows; one wavefront owns one slice for the whole pass:
-//       forward index (E-step, row sums): column-major [k][768]; lane l owns rows 12l..12l+11, so column j of its
-//         rows is ONE int4 of twelve 10-bit ids; padding points at a zero slot (no branches);
-//       backward index (M-step, column sums) OF THE SAME 768 ROWS: for every dictionary column with >= 4 entries in
-//         the slice, its slice-local rows cut into segments of 11 row ids headed by the column id
-//         (12 x 10 bit = one int4).  Segments are dealt to lanes in contiguous column order (a lane keeps the running
-//         sum of a column in a register), but stored interleaved so that wave loads stay 1 KiB contiguous.
-//         Columns with < 4 entries go to a COO list of (column, row) id pairs.
+//   * rows with 2..kMaxRowLen tids are sorted by (block(anchor tid), class of their number of entries, anchor tid), anchor = median
+//     tid, and cut into TILES of at most 3072 rows whose distinct tids fit a 360-slot tile-local DICTIONARY: the contiguous range
+//     [lo, lo+near_n) that covers most of the tile's tids plus an explicit list of far tids.  The dictionary is organised in blocks
+//     of three slots and every stored operand is a 10-BIT ENTRY = block * 8 + subset (see kBlk below), three to a dword;
+//   * a tile has up to 4 SLICES of 768 rows; one wavefront owns one slice for the whole pass; two consecutive tiles may share a
+//     dictionary (a unit, Tile::follows):
+//       forward index (E-step, row sums): column-major [k][768]; lane l owns rows l, l+64, ..., so column j of its
+//         rows is ONE int4 of twelve 10-bit entries; padding is entry 0, the empty subset (no branches);
+//       backward index (M-step, column sums) OF THE SAME 768 ROWS: for every entry value that occurs in the slice, its
+//         slice-local rows cut into segments of 11 row ids headed by the entry value (12 x 10 bit = one int4).  Segments are
+//         dealt to lanes in contiguous entry order (a lane keeps the running sum of a column in a register), but stored
+//         interleaved so that wave loads stay 1 KiB contiguous.  (kDenseMin > 1 sends rarer entries to a COO list of
+//         (entry, row) pairs: off, it costs more than a mostly empty segment.)
 //     Because the transposed index is per slice, the wave that computed w_r for its 768 rows is the only consumer
 //     of them: E-step and M-step need no workgroup barrier in between;
 //   * rows longer than kMaxRowLen go to a leftover CSR processed by the generic kernel.
@@ -109,7 +110,7 @@ struct Tile {                // 64 bytes
     uint32_t far_off;        // index of the tile's first far tid in far_tid[]
     uint32_t coo_off;        // index of the tile's first pair in coo[]
     int32_t lo;              // dictionary slot d < near_n  <->  tid lo + d
-    uint16_t near_n, far_n;  // slot near_n + i <-> far_tid[far_off + i]; zero slot = near_n + far_n
+    uint16_t near_n, far_n;  // slot near_n + i <-> far_tid[far_off + i]; slots near_n + far_n .. 359 are empty (theta 0)
     uint16_t n_slices;       // <= 4
     uint16_t follows;        // 1: this tile uses the dictionary of the tile before it (second half of a unit of up to 8 slices)
     uint16_t k[4];           // padded row length of each slice's forward index
@@ -163,7 +164,7 @@ inline void run_on_threads(int nt, F fn) {
 // Every address the pass kernels form from a tile descriptor, checked against the arrays as they are uploaded (the device arrays
 // have exactly these sizes).  The kernels read, per slice s < n_slices of a tile: k[s] forward columns of 256 dwords, m[s] backward
 // units of 64 int4, coo_n[s] COO words; far_n far tids; theta / acc at lo .. lo + near_n and at the far tids; the row weights and row
-// values at the 768 slots of the slice.  Every stored 10-bit id must name a dictionary slot (<= near_n + far_n, the zero slot), every
+// values at the 768 slots of the slice.  Every stored 10-bit entry must name a block and a subset whose slots exist (< near_n + far_n), every
 // stored row id a row of the slice (<= 768, the padding row).  0 = fine, -20 .. -29 = the first descriptor that is not.
 // Runs at the end of build_tiled (an upload never happens with a bad descriptor) and again in emsar_hip_layout_selfcheck_tiled.
 inline int check_tiled_extents(const TiledLayout &L) {
