@@ -156,9 +156,13 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i, parse_job *parse
     double t_host = now_s();
     den = (double *)calloc(T, sizeof(double));
     if (!den) { rc = EMSAR_HOST_ERR_OOM; goto done; }
+    /* ... and compute_iEUMA (emsar_functions.c:3218: iEUMA_t = sum of adjEUMA over the segments that hold t) in the same sweep, for the
+     * same reason: the eff.length and iReadcount columns are then the same bytes in every run */
+    memset(ieuma, 0, T * 8);
     for (int64_t c = 0; c < r->n_rows; c++) {
-        const double e = m->E_solver[c];
+        const double e = m->E_solver[c], l = m->L[c];
         if (e != 0.0) for (uint64_t k = r->row_ptr[c]; k < r->row_ptr[c + 1]; k++) den[r->col_idx[k]] += e;
+        if (l != 0.0) for (uint64_t k = r->row_ptr[c]; k < r->row_ptr[c + 1]; k++) ieuma[r->col_idx[k]] += l;
     }
     w->host_s[i] = w->model_s[i] + (now_s() - t_host);
     if ((rc = emsar_hip_upload_sample(ctx, cnt->R, m->E_solver, den)) ||
@@ -169,8 +173,7 @@ static int run_sample(worker_arg *w, emsar_hip_ctx *ctx, int i, parse_job *parse
     for (int k = 0; k < cfg->n_round; k++) memcpy(rounds + (size_t)k * T, theta, T * 8);   /* deterministic solver: rounds coincide */
     emsar_mean_sd(r->n_tx, cfg->n_round, rounds, mean, sd);
     /* ---- compute_iEUMA + print_FPKMfinal, emsar_main.c:454-460 ---- */
-    if ((rc = emsar_hip_ieuma(ctx, m->L, ieuma)) ||
-        (rc = emsar_hip_normalise(ctx, mean, ieuma, cnt->total_reads, tpm, ir, iri))) {
+    if ((rc = emsar_hip_normalise(ctx, mean, ieuma, cnt->total_reads, tpm, ir, iri))) {
         fprintf(stderr, "alnfile[%d]: %s (%s)\n", i, emsar_hip_strerror(rc), emsar_hip_last_error(ctx));
         goto done;
     }

@@ -164,6 +164,24 @@ def _reads(path, n_tx, length, n=400, seed=0):
             f.write("r%d\t+\tt%d\t1\t%s\t%s\t0\t\n" % (i, int(rng.integers(n_tx)), "A" * length, "I" * length))
 
 
+@pytest.mark.parametrize("extra", [[], ["--streaming-only"], ["--streaming-only", "--plain"]])
+def test_two_runs_write_the_same_bytes(tmp_path, extra):
+    """The reference's output changes from run to run (concurrent rand(), emsar_functions.c:3079).  Ours must not: the per-set solver
+    has no atomics, the streaming passes add in fixed point (deterministic mode, the CLI default), den and iEUMA are summed on
+    the host in row order -- every output file of two runs is the same bytes, also when the whole matrix goes through the
+    streaming kernels."""
+    fx = get_fixture("syn2k_se")
+    blobs = []
+    for tag in ("a", "b"):
+        d = tmp_path / tag
+        cmd = [CLI, "-q", "-g"] + extra + fx.meta["opts"] + ["-I", os.path.join(fx.dir, "index.rsh"), str(d), "out", _aln(fx)]
+        subprocess.run(cmd, check=True, timeout=300)
+        files = sorted(os.listdir(d))
+        assert len(files) >= 3
+        blobs.append([(f, open(os.path.join(d, f), "rb").read()) for f in files])
+    assert blobs[0] == blobs[1]
+
+
 def test_two_workers_share_one_card_with_eumacut_handover_and_a_failing_sample(tmp_path):
     """-M with two workers on device 0 (--devices 0,0): five samples, one of them missing.  The workers build their models
     concurrently from the EUMAcut they see and hand the value over in sample order; the 31-nt sample (index 0) raises it to 52,
