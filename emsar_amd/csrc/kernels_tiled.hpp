@@ -116,7 +116,9 @@ __device__ __forceinline__ void tile_acc_add(double *acc_w, unsigned off, double
 // Thread b < 120 owns block b in both directions: it fetches the block's three theta values, writes the eight subset sums
 // T[8b + m] and clears the eight accumulators W[8b + m]; at the end of the tile it folds the eight W words into its three
 // transcripts (transcript i of the block collects the subsets that hold it) and sends them to the global accumulator.
-struct BlockDict { double th[kBlk]; int tid[kBlk]; };
+struct BlockDict { double th[kBlk]; int tid[kBlk]; int stid[2]; };     // stid: the transcripts of SLOTS threadIdx.x and threadIdx.x + 256 (flush)
+constexpr int kSlotsPerThread = (emsar::kTileDict + kTiledThreads - 1) / kTiledThreads;
+static_assert(kSlotsPerThread == 2, "BlockDict::stid");
 template <int MODE>
 __device__ __forceinline__ void block_dict_issue(const Tile &T, int nd, const int32_t *far_tid, const double *theta, BlockDict &D) {
 #pragma unroll
@@ -127,6 +129,11 @@ __device__ __forceinline__ void block_dict_issue(const Tile &T, int nd, const in
             D.tid[i] = d < (int)T.near_n ? T.lo + d : __builtin_nontemporal_load(&far_tid[T.far_off + (d - (int)T.near_n)]);
             if (MODE != MODE_SCATTER) D.th[i] = theta[D.tid[i]];
         }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int sl = (int)threadIdx.x + j * kTiledThreads;
+        D.stid[j] = sl < nd ? (sl < (int)T.near_n ? T.lo + sl : __builtin_nontemporal_load(&far_tid[T.far_off + (sl - (int)T.near_n)])) : -1;
     }
 }
 __device__ __forceinline__ void block_dict_store(const BlockDict &D, double *th_w, double *acc_w) {
@@ -144,35 +151,34 @@ __device__ __forceinline__ void block_dict_store(const BlockDict &D, double *th_
         for (int m = 0; m < NE; m++) { t[m] = v[m]; a[m] = 0.0; }
     }
 }
+// The flush is by SLOT, not by block: thread s (and s + 256) folds the subsets of its block that hold slot s and sends the sum to
+// its transcript -- consecutive lanes add to consecutive transcripts of the near range, 512 contiguous bytes per wave instruction
+// (device-scope float atomics run at full rate only on contiguous addresses; by block, a lane's three adds were 24 bytes apart).
 __device__ __forceinline__ void block_dict_flush(const BlockDict &D, const double *th_w, const double *acc_w, double *acc, double fx) {
     constexpr int NE = emsar::kBlkEntries;
-    if (threadIdx.x >= emsar::kDictBlocks || D.tid[0] < 0) return;
-    const double *a = acc_w + threadIdx.x * NE;
-    double c[NE];
-    if (fx != 0.0) {
-        // deterministic mode: W[e] holds, as an integer, the MASS of entry e (sum of w_r T[e] fx over its rows: tile_acc_add);
-        // the column sum of the entry is that over T[e], transcript i gets theta_i times the sum over the subsets that hold it
-        const double *t = th_w + threadIdx.x * NE;
 #pragma unroll
-        for (int m = 1; m < NE; m++) { const double tm = t[m]; c[m] = tm > 0.0 ? (double)__double_as_longlong(a[m]) / tm : 0.0; }
-#pragma unroll
-        for (int i = 0; i < kBlk; i++) {
-            if (D.tid[i] < 0) continue;
+    for (int j = 0; j < 2; j++) {
+        const int tid = D.stid[j];
+        if (tid < 0) continue;
+        const int sl = (int)threadIdx.x + j * kTiledThreads, b = sl / kBlk, i = sl - b * kBlk;
+        const double *a = acc_w + b * NE;
+        if (fx != 0.0) {
+            // deterministic mode: W[e] holds, as an integer, the MASS of entry e (sum of w_r T[e] fx over its rows: tile_acc_add);
+            // the column sum of the entry is that over T[e], the slot's transcript gets its theta times the sum over the subsets that hold it
+            const double *t = th_w + b * NE;
             double si = 0.0;
 #pragma unroll
-            for (int m = 1; m < NE; m++) if (m >> i & 1) si += c[m];
+            for (int m = 1; m < NE; m++) {
+                const double tm = t[m];
+                if ((m >> i & 1) && tm > 0.0) si += (double)__double_as_longlong(a[m]) / tm;
+            }
             const long long iv = __double2ll_rn(t[1 << i] * si);
-            if (iv != 0) atomic_add_i64(&acc[D.tid[i]], iv);
-        }
-    } else {
-#pragma unroll
-        for (int m = 1; m < NE; m++) c[m] = a[m];
-#pragma unroll
-        for (int i = 0; i < kBlk; i++) {
+            if (iv != 0) atomic_add_i64(&acc[tid], iv);
+        } else {
             double si = 0.0;
 #pragma unroll
-            for (int m = 1; m < NE; m++) if (m >> i & 1) si += c[m];
-            if (D.tid[i] >= 0 && si != 0.0) atomic_add_f64(&acc[D.tid[i]], si);
+            for (int m = 1; m < NE; m++) if (m >> i & 1) si += a[m];
+            if (si != 0.0) atomic_add_f64(&acc[tid], si);
         }
     }
 }
