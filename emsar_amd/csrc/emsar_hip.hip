@@ -248,15 +248,16 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
 
 // a likelihood word of the host copy of the scalars (fixed point in deterministic mode)
 inline double host_ll(const emsar_hip_ctx *ctx, int i) {
-    const double v = ctx->h_scal->ll[i].v;
-    if (!ctx->det || ctx->fx_ll == 0.0) return v;
-    long long b; memcpy(&b, &v, 8);
+    const LlSum &L = ctx->h_scal->ll[i];             // the words of the sum, added in a fixed order (kernels_common.hpp)
+    if (!ctx->det || ctx->fx_ll == 0.0) { double v = 0.0; for (int j = 0; j < kLlSlots; j++) v += L.s[j].v; return v; }
+    long long b = 0;
+    for (int j = 0; j < kLlSlots; j++) { long long x; memcpy(&x, &L.s[j].v, 8); b += x; }
     return (double)b / ctx->fx_ll;
 }
 
 // th_out = EM(th_in); ll slot receives sum R log S at th_in when want_ll
 int em_pass(emsar_hip_ctx *ctx, const double *th_in, double *th_out, bool want_ll, int ll_slot, double abs_floor, int to_delta1 = 0) {
-    int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot].v);
+    int rc = launch_pass(ctx, want_ll ? MODE_EM_LL : MODE_EM, th_in, ctx->d_acc, &ctx->d_scal->ll[ll_slot].s[0].v);
     if (rc) return rc;
     hipLaunchKernelGGL(k_update, dim3(std::min(grid_for(ctx->n_tx, 256), ctx->update_grid)), dim3(256), 0, ctx->stream, ctx->n_tx, th_in, ctx->d_acc,
                        ctx->d_den, ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr, th_out, abs_floor, ctx->count_floor, ctx->zero_cut, ctx->d_scal,
@@ -273,7 +274,7 @@ int enqueue_cycles(emsar_hip_ctx *ctx, const emsar_em_params &p, double abs_step
     double **th = ctx->d_th;
     int rc;
     for (int c = 0; c < cycles; c++) {
-        hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal, abs_step_base, p.accel ? 3 : 1);
+        hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(kLlSlots), 0, ctx->stream, ctx->d_scal, abs_step_base, p.accel ? 3 : 1);
         if (!p.accel) {
             if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor))) return rc;
             std::swap(th[0], th[1]);
@@ -283,10 +284,10 @@ int enqueue_cycles(emsar_hip_ctx *ctx, const emsar_em_params &p, double abs_step
         const double *u = ctx->layout == EMSAR_LAYOUT_TILED ? ctx->d_u : nullptr;
         const dim3 gv((unsigned)std::min(std::min(g, ctx->sq_grid), kSqPart)), bv(256);
         if ((rc = em_pass(ctx, th[0], th[1], false, 0, p.abs_floor, 1))) return rc;
-        if ((rc = launch_pass(ctx, MODE_EM_LL, th[1], ctx->d_acc, &ctx->d_scal->ll[1].v, true))) return rc;
+        if ((rc = launch_pass(ctx, MODE_EM_LL, th[1], ctx->d_acc, &ctx->d_scal->ll[1].s[0].v, true))) return rc;
         hipLaunchKernelGGL(k_update_p2, gv, bv, 0, ctx->stream, n, th[0], th[1], ctx->d_acc, ctx->d_den, u, th[2], ctx->d_scal, ctx->d_sqpart, fx_of(ctx));
         hipLaunchKernelGGL(k_sq_extrap_ll, gv, bv, 0, ctx->stream, n, th[0], th[1], th[2], ctx->d_den, u, th[3], ctx->d_scal, ctx->d_sqpart, (int)gv.x, fx_of(ctx));
-        if ((rc = launch_pass(ctx, MODE_EM_LL, th[3], ctx->d_acc, &ctx->d_scal->ll[2].v, true))) return rc;
+        if ((rc = launch_pass(ctx, MODE_EM_LL, th[3], ctx->d_acc, &ctx->d_scal->ll[2].s[0].v, true))) return rc;
         hipLaunchKernelGGL(k_update_p3, gv, bv, 0, ctx->stream, n, th[3], th[2], ctx->d_acc, ctx->d_den, u, th[0], ctx->d_scal, ctx->d_sqpart, (int)gv.x, fx_of(ctx));
         HIPCHK(hipGetLastError());
     }
@@ -787,7 +788,7 @@ int emsar_hip_run_passes(emsar_hip_ctx *ctx, int32_t n_passes, float *elapsed_ms
     if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
     HIPCHK(hipSetDevice(ctx->device));
     ctx->delta_mask = nullptr;
-    hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal, 0.0, 0);
+    hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(kLlSlots), 0, ctx->stream, ctx->d_scal, 0.0, 0);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int cur = 0;  // th[cur] holds the current point, th[cur^1] receives the next
     for (int i = 0; i < n_passes; i++) {
@@ -893,10 +894,10 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
     }
     HIPCHK(hipEventRecord(ctx->ev2, ctx->stream));
     // F at the returned point: one likelihood-only pass (not counted in iters)
-    hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal, 0.0, 0);
-    if ((rc = launch_pass(ctx, MODE_EM_LL, th[0], ctx->d_acc, &ctx->d_scal->ll[0].v))) return rc;
+    hipLaunchKernelGGL(k_cycle_begin, dim3(1), dim3(kLlSlots), 0, ctx->stream, ctx->d_scal, 0.0, 0);
+    if ((rc = launch_pass(ctx, MODE_EM_LL, th[0], ctx->d_acc, &ctx->d_scal->ll[0].s[0].v))) return rc;
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)n * 8, ctx->stream));
-    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, ctx->stream, n, th[0], ctx->d_den, &ctx->d_scal->ll[3].v);
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, ctx->stream, n, th[0], ctx->d_den, &ctx->d_scal->ll[3].s[0].v);
     HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(fpkm_out, th[0], (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -935,7 +936,7 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
         stats->iters = iters + set_max;
         stats->converged = converged;
         stats->final_delta = delta;
-        stats->loglik = host_ll(ctx, 0) + ctx->loglik_const - ctx->h_scal->ll[3].v;
+        stats->loglik = host_ll(ctx, 0) + ctx->loglik_const - ctx->h_scal->ll[3].s[0].v;
         stats->kernel_ms = ms + (use_sets ? ms_sets : 0.0f);
         stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         stats->bytes_per_pass = ctx->bytes_formula;
@@ -1058,7 +1059,7 @@ int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
     const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
     HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<false, MODE_EM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_pass_tiled<false, MODE_EM, true>), dim3((unsigned)ctx->n_tiles), dim3(kTiledThreads), lds, ctx->stream, ctx->d_tiles,
-                       ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].v, Fx{0.0, 0.0}, d);
+                       ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].s[0].v, Fx{0.0, 0.0}, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
     std::vector<unsigned long long> h(nw * 8);

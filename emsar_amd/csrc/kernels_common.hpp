@@ -15,8 +15,13 @@ struct alignas(128) LineF64 {
     __host__ __device__ operator double() const { return v; }
     __host__ __device__ LineF64 &operator=(double x) { v = x; return *this; }
 };
+// A likelihood sum receives one add per workgroup of a pass kernel -- 4.4 k adds on config 3, and same-address atomics are served
+// one after another (~5 ns each: 23 us of a 134 us likelihood pass).  So the sum is kept in kLlSlots words on lines of their own,
+// workgroup b adds to word b % kLlSlots, and whoever needs the value adds the words up (ll_value / host_ll).
+constexpr int kLlSlots = 64;
+struct LlSum { LineF64 s[kLlSlots]; };
 struct Scal {
-    LineF64 ll[4];                // sum_c R_c log S_c at the input of pass 0/1/2 of the cycle; [3] scratch
+    LlSum ll[4];                  // sum_c R_c log S_c at the input of pass 0/1/2 of the cycle; [3] scratch
     LineF64 sr2, sv2, pen1, penx; // SQUAREM norms, sum theta*den of th1 and of the extrapolated point
     double stepmax, s_used;
     unsigned long long delta_bits;  // max_t |dtheta|/(theta+floor) as IEEE bits (non-negative -> integer max)
@@ -53,13 +58,21 @@ __device__ __forceinline__ void lds_add_i64(double *p, long long v) {
     __hip_atomic_fetch_add(reinterpret_cast<long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // a likelihood partial sum of one workgroup -> the shared word (fixed point when fx_ll != 0)
-__device__ __forceinline__ void ll_add(double *ll_out, double t, double fx_ll) {
-    if (fx_ll != 0.0) atomic_add_i64(ll_out, __double2ll_rn(t * fx_ll));
-    else atomic_add_f64(ll_out, t);
+__device__ __forceinline__ void ll_add(double *ll_out /* word 0 of an LlSum */, double t, double fx_ll) {
+    double *p = ll_out + (blockIdx.x % kLlSlots) * (sizeof(LineF64) / sizeof(double));
+    if (fx_ll != 0.0) atomic_add_i64(p, __double2ll_rn(t * fx_ll));
+    else atomic_add_f64(p, t);
 }
-// the value of such a word
-__device__ __forceinline__ double ll_value(const double *p, double fx_ll) {
-    return fx_ll != 0.0 ? (double)__double_as_longlong(*p) / fx_ll : *p;
+// the value of such a sum: its words added in a fixed order
+__device__ __forceinline__ double ll_value(const double *ll_word0, double fx_ll) {
+    if (fx_ll != 0.0) {
+        long long s = 0;
+        for (int i = 0; i < kLlSlots; i++) s += __double_as_longlong(ll_word0[i * (sizeof(LineF64) / sizeof(double))]);
+        return (double)s / fx_ll;
+    }
+    double s = 0.0;
+    for (int i = 0; i < kLlSlots; i++) s += ll_word0[i * (sizeof(LineF64) / sizeof(double))];
+    return s;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

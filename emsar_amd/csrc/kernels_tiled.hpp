@@ -236,24 +236,33 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 }
 
 // sum_i log S_i over a lane's kRPL unweighted rows (S_i <= 0: row outside F or padding, no term) with two logs instead of
-// twelve: log of the product of six row sums.  A product that leaves [1e-280, 1e280] (components decayed towards the
+// twelve: log of the product of the twelve row sums of a lane (of six, of one, as the range allows).  A product that leaves [1e-280, 1e280] (components decayed towards the
 // boundary) falls back to the per-row logs.  The f64 log is ~40 VALU instructions: 19 % of a likelihood pass on config 3.
-template <int N>
-__device__ __forceinline__ double sum_log_rows(const double (&S)[N]) {
-    static_assert(N % 6 == 0, "rows per lane");
+// (the fallback is one out-of-line loop: fifteen inlined copies of the f64 log made the likelihood variant of the unit kernel 65 KB
+// of code, more than the instruction cache two CUs share)
+__device__ __noinline__ double sum_log_rows_slow(const double *S /* LDS: row i of the lane at S[64 i] */, int n) {
     double ll = 0.0;
+    for (int i = 0; i < n; i++) { const double v = S[64 * i]; if (v > 0.0) ll += log(v); }
+    return ll;
+}
+// w_s: the wave's own row-weight region of LDS, free at this point of the E-step (written right afterwards): scratch of the fallback
+template <int N>
+__device__ __forceinline__ double sum_log_rows(const double (&S)[N], double *w_s, int lane) {
+    static_assert(N == 12, "rows per lane");
+    double h[2];
 #pragma unroll
-    for (int g = 0; g < N; g += 6) {
+    for (int g = 0; g < 2; g++) {
         double p = 1.0;
 #pragma unroll
-        for (int i = g; i < g + 6; i++) p *= S[i] > 0.0 ? S[i] : 1.0;
-        if (p > 1e-280 && p < 1e280) ll += log(p);
-        else {
-#pragma unroll
-            for (int i = g; i < g + 6; i++) if (S[i] > 0.0) ll += log(S[i]);
-        }
+        for (int i = 6 * g; i < 6 * g + 6; i++) p *= S[i] > 0.0 ? S[i] : 1.0;
+        h[g] = p;
     }
-    return ll;
+    // one log for all twelve rows when the product stays inside the range (the usual case: row sums are inferred read
+    // densities, 1e-3 .. 1e5); else one per row
+    if (h[0] > 1e-140 && h[0] < 1e140 && h[1] > 1e-140 && h[1] < 1e140) return log(h[0] * h[1]);
+#pragma unroll
+    for (int i = 0; i < N; i++) w_s[64 * i + lane] = S[i];
+    return sum_log_rows_slow(w_s + lane, N);
 }
 
 template <bool WEIGHTED, int MODE, bool STAMP = false>
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
                 w[i] = live ? r[i] / S[i] : 0.0;
                 if (MODE == MODE_EM_LL && WEIGHTED && live) ll += r[i] * log(S[i]);
             }
-            if (MODE == MODE_EM_LL && !WEIGHTED) ll += sum_log_rows(S);
+            if (MODE == MODE_EM_LL && !WEIGHTED) ll += sum_log_rows(S, w_s, lane);
         }
 #pragma unroll
         for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = w[i];
@@ -439,7 +448,7 @@ __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], siz
         w[i] = live ? r[i] / S[i] : 0.0;
         if (MODE == MODE_EM_LL && WEIGHTED && live) ll += r[i] * log(S[i]);
     }
-    if (MODE == MODE_EM_LL && !WEIGHTED) ll += sum_log_rows(S);
+    if (MODE == MODE_EM_LL && !WEIGHTED) ll += sum_log_rows(S, w_s, lane);
 #pragma unroll
     for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = w[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

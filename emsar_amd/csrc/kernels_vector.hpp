@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void k_update(int n, const double *__restrict_
 
 // abs_step_base > 0: the projected-drift bound of emsar_em_params.abs_step, |dtheta| < base * 2e5 / K at pass K >= 1000.  K is
 // counted here, on the device, so that a cycle recorded once in a hipGraph carries the right bound at every replay.
-__global__ void k_cycle_begin(Scal *s, double abs_step_base, int passes_in_cycle) {
-    for (int i = 0; i < 4; i++) s->ll[i] = 0.0;
+__global__ __launch_bounds__(kLlSlots) void k_cycle_begin(Scal *s, double abs_step_base, int passes_in_cycle) {   // one workgroup of kLlSlots threads
+    for (int i = 0; i < 4; i++) s->ll[i].s[threadIdx.x] = 0.0;
+    if (threadIdx.x != 0) return;
     s->sr2 = 0.0; s->sv2 = 0.0; s->pen1 = 0.0; s->penx = 0.0;
     s->delta_bits = 0ull; s->delta1_bits = 0ull;
     const long long done = s->passes;
@@ -94,6 +95,28 @@ __device__ __forceinline__ double sq_sum(const double *__restrict__ part, int n,
     __syncthreads();
     return all;
 }
+// the value of a likelihood sum (kLlSlots words, kernels_common.hpp) for every thread of a 256-thread workgroup: the first wave
+// loads one word per lane and adds them up in a fixed butterfly, the result goes round through LDS
+__device__ __forceinline__ double ll_value_wg(const double *ll_word0, double fx_ll, double *red) {
+    static_assert(kLlSlots == 64, "one word per lane of a wave");
+    if (threadIdx.x < 64) {
+        const double w = ll_word0[threadIdx.x * (sizeof(LineF64) / sizeof(double))];
+        double v;
+        if (fx_ll != 0.0) {
+            long long x = __double_as_longlong(w);
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+            v = (double)x / fx_ll;
+        } else {
+            v = w;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        }
+        if (threadIdx.x == 0) red[0] = v;
+    }
+    __syncthreads();
+    const double all = red[0];
+    __syncthreads();
+    return all;
+}
 __global__ __launch_bounds__(256) void k_update_p2(int n, const double *__restrict__ th0, const double *__restrict__ th1, double *__restrict__ acc,
                                                    const double *__restrict__ den, const double *__restrict__ u, double *__restrict__ th2, Scal *scal,
                                                    double *__restrict__ part, Fx fx) {
@@ -114,7 +137,7 @@ __global__ __launch_bounds__(256) void k_update_p2(int n, const double *__restri
     double d = block_sum<256>(l1, red);
     if (threadIdx.x == 0) {       // |r|^2, |v|^2, sum theta*den: one word per workgroup, summed in a fixed order by the kernels that use them (sq_sum)
         part[blockIdx.x] = a; part[kSqPart + blockIdx.x] = b; part[2 * kSqPart + blockIdx.x] = c;
-        if (d != 0.0) ll_add(&scal->ll[1].v, d, fx.ll);
+        if (d != 0.0) ll_add(&scal->ll[1].s[0].v, d, fx.ll);
     }
 }
 __global__ __launch_bounds__(256) void k_sq_extrap_ll(int n, const double *__restrict__ th0, const double *__restrict__ th1,
@@ -141,7 +164,7 @@ __global__ __launch_bounds__(256) void k_sq_extrap_ll(int n, const double *__res
     double l = block_sum<256>(lx, red);
     if (threadIdx.x == 0) {
         part[3 * kSqPart + blockIdx.x] = p;
-        if (l != 0.0) ll_add(&scal->ll[2].v, l, fx.ll);
+        if (l != 0.0) ll_add(&scal->ll[2].s[0].v, l, fx.ll);
         if (blockIdx.x == 0) { scal->s_used = extrap ? s : 1.0; scal->sr2 = sr2; scal->sv2 = sv2; }
     }
 }
@@ -152,7 +175,8 @@ __global__ __launch_bounds__(256) void k_update_p3(int n, const double *__restri
     const double s = scal->s_used;
     const bool extrap = s > 1.0;
     const double pen1 = sq_sum(part + 2 * kSqPart, n_part, red), penx = sq_sum(part + 3 * kSqPart, n_part, red);
-    const bool ok = !extrap || (ll_value(&scal->ll[2].v, fx.ll) - penx >= ll_value(&scal->ll[1].v, fx.ll) - pen1);
+    const double ll2 = ll_value_wg(&scal->ll[2].s[0].v, fx.ll, red), ll1 = ll_value_wg(&scal->ll[1].s[0].v, fx.ll, red);
+    const bool ok = !extrap || (ll2 - penx >= ll1 - pen1);
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
         const double y = em_new_theta(thx[t], acc[t], den[t], u, t, fx.mass);
         acc[t] = 0.0;
