@@ -436,7 +436,7 @@ __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], siz
     for (int j0 = 0; j0 < W.k; j0 += 8) {
         const int n0 = W.k - j0 < 8 ? W.k - j0 : 8;
         if (j0) load8_clamped(A, W.e + (size_t)j0 * 64, n0);
-        fwd_sum_regs<6>(A, n0, th_base, S);
+        fwd_sum_regs<EMSAR_UE_BATCH>(A, n0, th_base, S);
     }
     if (WEIGHTED) {
 #pragma unroll
@@ -462,7 +462,7 @@ __device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], con
     for (int j0 = 0; j0 < W.m; j0 += 8) {
         const int n0 = W.m - j0 < 8 ? W.m - j0 : 8;
         if (j0) load8_clamped(B, W.b + (size_t)j0 * 64, n0);
-        bwd_sum_regs<6>(B, n0, ws_base, acc_w, cur, part, fx);
+        bwd_sum_regs<EMSAR_UM_BATCH>(B, n0, ws_base, acc_w, cur, part, fx);
     }
     if (part != 0.0) tile_acc_add(acc_w, cur, part, fx);
     for (unsigned q = lane; q < W.coo_n; q += 64) {
