@@ -20,6 +20,12 @@ namespace {
 // k_pass_tiled_unit (the default above 2048 tiles): the same for a UNIT of up to two tiles that share one dictionary.
 // HBM traffic: 10 bits per forward slot + 128 bits per 11 backward entries -- no row_ptr, no 32-bit tids.
 // ------------------------------------------------------------------------------------------------
+#ifndef EMSAR_UE_BATCH          // LDS gathers in flight per step of the E / M loops of the unit and multi kernels (tile_e_step,
+#define EMSAR_UE_BATCH 6        // tile_m_step); 6 / 12 in any combination measured 0.1159 - 0.1165 ms: no difference
+#endif
+#ifndef EMSAR_UM_BATCH
+#define EMSAR_UM_BATCH 6
+#endif
 constexpr int kTiledThreads = 256;                       // 4 wavefronts = 4 slices
 constexpr int kRPL = emsar::kRowsPerLane;                 // 12 rows per lane = twelve 10-bit ids per int4
 constexpr int kTiledWr = emsar::kTileSliceRows + 8;       // w_r of one slice (768) + the zero padding row
