@@ -397,8 +397,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     int64_t tile_rows = kTileRows;
     int unit_tiles = 2;                 // tiles that may share one dictionary (a unit: one workgroup, one dictionary load, one flush)
     if (const char *e = getenv("EMSAR_HIP_UNIT_TILES")) { int v = atoi(e); if (v >= 1 && v <= 2) unit_tiles = v; }
-    const int64_t unit_rows = tile_rows * unit_tiles;
     if (const char *e = getenv("EMSAR_HIP_TILE_ROWS")) { int v = atoi(e); if (v >= kTileSliceRows && v <= kTileRows) tile_rows = v / kTileSliceRows * kTileSliceRows; }
+    const int64_t unit_rows = tile_rows * unit_tiles;
     int dense_min = kDenseMin;
     if (const char *e = getenv("EMSAR_HIP_TILE_DENSE")) { int v = atoi(e); if (v >= 1 && v <= 64) dense_min = v; }
     bool cut_at_slices = true;
