@@ -244,13 +244,8 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 // sum_i log S_i over a lane's kRPL unweighted rows (S_i <= 0: row outside F or padding, no term) with two logs instead of
 // twelve: log of the product of the twelve row sums of a lane (of six, of one, as the range allows).  A product that leaves [1e-280, 1e280] (components decayed towards the
 // boundary) falls back to the per-row logs.  The f64 log is ~40 VALU instructions: 19 % of a likelihood pass on config 3.
-// (the fallback is one out-of-line loop: fifteen inlined copies of the f64 log made the likelihood variant of the unit kernel 65 KB
-// of code, more than the instruction cache two CUs share)
-__device__ __noinline__ double sum_log_rows_slow(const double *S /* LDS: row i of the lane at S[64 i] */, int n) {
-    double ll = 0.0;
-    for (int i = 0; i < n; i++) { const double v = S[64 * i]; if (v > 0.0) ll += log(v); }
-    return ll;
-}
+// (the fallback is a rolled loop over LDS: fifteen inlined copies of the f64 log made the likelihood variant of the unit kernel
+// 65 KB of code, more than the instruction cache two CUs share; an out-of-line function cost scratch for its call frame)
 // w_s: the wave's own row-weight region of LDS, free at this point of the E-step (written right afterwards): scratch of the fallback
 template <int N>
 __device__ __forceinline__ double sum_log_rows(const double (&S)[N], double *w_s, int lane) {
@@ -268,7 +263,10 @@ __device__ __forceinline__ double sum_log_rows(const double (&S)[N], double *w_s
     if (h[0] > 1e-140 && h[0] < 1e140 && h[1] > 1e-140 && h[1] < 1e140) return log(h[0] * h[1]);
 #pragma unroll
     for (int i = 0; i < N; i++) w_s[64 * i + lane] = S[i];
-    return sum_log_rows_slow(w_s + lane, N);
+    double ll = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < N; i++) { const double v = w_s[64 * i + lane]; if (v > 0.0) ll += log(v); }     // ONE copy of the log in the code
+    return ll;
 }
 
 template <bool WEIGHTED, int MODE, bool STAMP = false>
@@ -561,10 +559,8 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *th_w = lds, *acc_w = lds + kTiledDictPad, *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;
     const uint32_t t0 = unit_first[blockIdx.x], t1 = unit_first[blockIdx.x + 1];
-    const Tile T = tiles[t0];
-    const bool two = t1 - t0 > 1;
-    const Tile T2 = tiles[two ? t0 + 1 : t0];
-    const TileWave W = tile_wave(T, wave, lane, fwd, bwd);
+    Tile T = tiles[t0];
+    TileWave W = tile_wave(T, wave, lane, fwd, bwd);
     BlockDict D;
     int4 A[8], B[8];
     block_dict_issue<MODE>(T, W.nd, far_tid, theta, D);
@@ -576,15 +572,16 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     block_dict_store(D, th_w, acc_w);
     __syncthreads();
     double ll = 0.0;
-    if (W.has_slice) tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)wave * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
-    TileWave W2 = tile_wave(T2, wave, lane, fwd, bwd);
-    if (!two) W2.has_slice = false;
-    if (W2.has_slice) load8_clamped(A, W2.e, W2.k < 8 ? W2.k : 8);
-    if (W.has_slice) tile_m_step(W, B, coo, w_s, acc_w, lane, fx.mass);
-    if (W2.has_slice) {
-        if (W2.m > 0) load8_clamped(B, W2.b, W2.m < 8 ? W2.m : 8);
-        tile_e_step<WEIGHTED, MODE>(W2, A, (size_t)T2.row_base + (size_t)wave * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
-        tile_m_step(W2, B, coo, w_s, acc_w, lane, fx.mass);
+    for (uint32_t t = t0; t < t1; t++) {              // the tiles of the unit, one after the other, on the same table
+        if (W.has_slice) tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)wave * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
+        const bool more = t + 1 < t1;
+        const Tile Tn = tiles[more ? t + 1 : t];
+        TileWave Wn = tile_wave(Tn, wave, lane, fwd, bwd);
+        if (!more) Wn.has_slice = false;
+        if (Wn.has_slice) load8_clamped(A, Wn.e, Wn.k < 8 ? Wn.k : 8);        // the next tile's forward columns during this one's M-step
+        if (W.has_slice) tile_m_step(W, B, coo, w_s, acc_w, lane, fx.mass);
+        if (Wn.has_slice && Wn.m > 0) load8_clamped(B, Wn.b, Wn.m < 8 ? Wn.m : 8);
+        T = Tn; W = Wn;
     }
     __syncthreads();
     block_dict_flush(D, th_w, acc_w, acc, fx.mass);

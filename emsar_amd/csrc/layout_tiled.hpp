@@ -71,6 +71,7 @@ constexpr int kSliceDwords = kTileSliceRows / 3;    // dwords per forward column
 // field i (0..11) of a packed int4: dword i/3, bits 10*(i%3) .. +10
 inline void pack10(uint32_t *q, int i, uint32_t id) { q[i / 3] |= (id & 0x3FFu) << (10 * (i % 3)); }
 inline uint32_t unpack10(const uint32_t *q, int i) { return (q[i / 3] >> (10 * (i % 3))) & 0x3FFu; }
+constexpr int kUnitMaxTiles = 4;       // tiles that may share one dictionary
 constexpr int kDenseMin = 1;           // columns with fewer entries in a slice use the COO list (1 = none: with block entries the COO path --
                                        // a load, an LDS read and an LDS atomic per entry -- costs more than a mostly empty segment: 4 / 2 / 1 -> 0.139 / 0.133 / 0.127 ms)
 // the entries (block * 8 + mask) of one row from its dictionary slots (any order; a slot that occurs twice -- an internal repeat
@@ -218,14 +219,15 @@ inline int check_tiled_extents(const TiledLayout &L) {
         if (T.follows > 1 || (T.follows && i == 0)) return -30;
         if (T.follows) {
             const Tile &P = L.tiles[i - 1];
-            if (P.follows || P.lo != T.lo || P.near_n != T.near_n || P.far_n != T.far_n || P.far_off != T.far_off) return -30;
+            if (P.lo != T.lo || P.near_n != T.near_n || P.far_n != T.far_n || P.far_off != T.far_off) return -30;
         }
     }
     if (!L.tiles.empty()) {
         if (L.unit_first.size() < 2 || L.unit_first.front() != 0 || L.unit_first.back() != L.tiles.size()) return -31;
         for (size_t u = 0; u + 1 < L.unit_first.size(); u++) {
             const uint32_t a = L.unit_first[u], b = L.unit_first[u + 1];
-            if (b <= a || b - a > 2 || b > L.tiles.size() || L.tiles[a].follows || (b - a == 2 && !L.tiles[a + 1].follows)) return -31;
+            if (b <= a || b - a > (uint32_t)kUnitMaxTiles || b > L.tiles.size() || L.tiles[a].follows) return -31;
+            for (uint32_t q = a + 1; q < b; q++) if (!L.tiles[q].follows) return -31;
         }
     }
     for (int64_t r : L.slot_row) if (r < -1 || r >= (L.merged ? (int64_t)L.mem_ptr.size() - 1 : L.n_rows)) return -20;
@@ -396,7 +398,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 900) block = v; }
     int64_t tile_rows = kTileRows;
     int unit_tiles = 2;                 // tiles that may share one dictionary (a unit: one workgroup, one dictionary load, one flush)
-    if (const char *e = getenv("EMSAR_HIP_UNIT_TILES")) { int v = atoi(e); if (v >= 1 && v <= 2) unit_tiles = v; }
+    if (const char *e = getenv("EMSAR_HIP_UNIT_TILES")) { int v = atoi(e); if (v >= 1 && v <= kUnitMaxTiles) unit_tiles = v; }
     if (const char *e = getenv("EMSAR_HIP_TILE_ROWS")) { int v = atoi(e); if (v >= kTileSliceRows && v <= kTileRows) tile_rows = v / kTileSliceRows * kTileSliceRows; }
     const int64_t unit_rows = tile_rows * unit_tiles;
     int dense_min = kDenseMin;
@@ -462,7 +464,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             while (i1 < n_act && i1 - i0 < unit_rows) {
                 uint32_t r = perm[(size_t)i1];
                 uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-                if (i1 > i0 && ents + (int64_t)(e - b) > 2 * kTileEntries) break;
+                if (i1 > i0 && ents + (int64_t)(e - b) > (int64_t)unit_tiles * kTileEntries) break;
                 size_t before = distinct.size();
                 for (uint64_t k = b; k < e; k++) {
                     int32_t t = col_idx[k];
