@@ -153,8 +153,9 @@ __device__ __forceinline__ void block_dict_store(const BlockDict &D, double *th_
             const int hi = 31 - __builtin_clz((unsigned)m);
             v[m] = v[m & ~(1 << hi)] + D.th[hi];
         }
+        const int sw = EMSAR_SWZ ? (int)(threadIdx.x & (NE - 1)) : 0;     // bank swizzle of the block (layout_tiled.hpp: entry_code)
 #pragma unroll
-        for (int m = 0; m < NE; m++) { t[m] = v[m]; a[m] = 0.0; }
+        for (int m = 0; m < NE; m++) { t[m ^ sw] = v[m]; a[m] = 0.0; }
     }
 }
 // The flush is by SLOT, not by block: thread s (and s + 256) folds the subsets of its block that hold slot s and sends the sum to
@@ -168,6 +169,7 @@ __device__ __forceinline__ void block_dict_flush(const BlockDict &D, const doubl
         if (tid < 0) continue;
         const int sl = (int)threadIdx.x + j * kTiledThreads, b = sl / kBlk, i = sl - b * kBlk;
         const double *a = acc_w + b * NE;
+        const int sw = EMSAR_SWZ ? (b & (NE - 1)) : 0;
         if (fx != 0.0) {
             // deterministic mode: W[e] holds, as an integer, the MASS of entry e (sum of w_r T[e] fx over its rows: tile_acc_add);
             // the column sum of the entry is that over T[e], the slot's transcript gets its theta times the sum over the subsets that hold it
@@ -175,15 +177,15 @@ __device__ __forceinline__ void block_dict_flush(const BlockDict &D, const doubl
             double si = 0.0;
 #pragma unroll
             for (int m = 1; m < NE; m++) {
-                const double tm = t[m];
-                if ((m >> i & 1) && tm > 0.0) si += (double)__double_as_longlong(a[m]) / tm;
+                const double tm = t[m ^ sw];
+                if ((m >> i & 1) && tm > 0.0) si += (double)__double_as_longlong(a[m ^ sw]) / tm;
             }
-            const long long iv = __double2ll_rn(t[1 << i] * si);
+            const long long iv = __double2ll_rn(t[(1 << i) ^ sw] * si);
             if (iv != 0) atomic_add_i64(&acc[tid], iv);
         } else {
             double si = 0.0;
 #pragma unroll
-            for (int m = 1; m < NE; m++) if (m >> i & 1) si += a[m];
+            for (int m = 1; m < NE; m++) if (m >> i & 1) si += a[m ^ sw];
             if (si != 0.0) atomic_add_f64(&acc[tid], si);
         }
     }
