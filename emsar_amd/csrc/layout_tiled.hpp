@@ -725,7 +725,9 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         out.unit_first.push_back((uint32_t)sorted_tiles.size());
         out.tiles.swap(sorted_tiles);
     }
-    if (dbg_t) fprintf(stderr, "build_tiled: total %.0f ms\n", t_ms(tp0, t_now()));
+    if (dbg_t) fprintf(stderr, "build_tiled: total %.0f ms; %zu tiles in %zu units, %lld slices, %lld entries in %lld padded operands, %lld far\n", t_ms(tp0, t_now()),
+                       out.tiles.size(), out.unit_first.empty() ? (size_t)0 : out.unit_first.size() - 1, (long long)out.n_fslices,
+                       (long long)out.tiled_entries, (long long)out.padded_slots, (long long)out.far_entries);
     const int ext = check_tiled_extents(out);       // nothing reaches the device unless every descriptor stays inside its arrays
     return ext == 0 ? 0 : ext;
 }
