@@ -118,50 +118,67 @@ __device__ __forceinline__ void tile_acc_add(double *acc_w, unsigned off, double
     if (fx != 0.0) lds_add_i64(p, __double2ll_rn(part * *(p - kTiledDictPad) * fx));
     else lds_add_f64(p, part);
 }
-// ---- the dictionary of a tile: blocks of three transcripts, eight subset sums each (layout_tiled.hpp) ----
-// Thread b < 120 owns block b in both directions: it fetches the block's three theta values, writes the eight subset sums
-// T[8b + m] and clears the eight accumulators W[8b + m]; at the end of the tile it folds the eight W words into its three
-// transcripts (transcript i of the block collects the subsets that hold it) and sends them to the global accumulator.
-struct BlockDict { double th[kBlk]; int tid[kBlk]; int stid[2]; };     // stid: the transcripts of SLOTS threadIdx.x and threadIdx.x + 256 (flush)
+// ---- the dictionary of a tile (layout_tiled.hpp): near blocks of three transcripts with eight subset sums each, then one entry
+// per far transcript ----
+// Thread b < nb (the tile's near blocks, <= 120) fetches the three theta of block b and writes the eight subset sums T[8b + m];
+// the other threads fetch three far transcripts each (far entry i lives at T[8 nb + i] = its theta).  Everybody clears the
+// accumulators of what it wrote.  At the end of the tile the near part is folded BY SLOT: thread s (and s + 256) adds up the
+// subsets of its block that hold slot s and sends the sum to its transcript -- consecutive lanes add to consecutive transcripts,
+// 512 contiguous bytes per wave instruction (device-scope float atomics run at full rate only on contiguous addresses); a far
+// entry is flushed by the thread that fetched it.
+struct BlockDict { double th[kBlk]; int tid[kBlk]; int stid[2]; };     // stid: the transcripts of near SLOTS threadIdx.x and threadIdx.x + 256
 constexpr int kSlotsPerThread = (emsar::kTileDict + kTiledThreads - 1) / kTiledThreads;
 static_assert(kSlotsPerThread == 2, "BlockDict::stid");
+static_assert(emsar::kFarMax == kBlk * (kTiledThreads - emsar::kDictBlocks), "three far entries per thread that owns no near block");
 template <int MODE>
 __device__ __forceinline__ void block_dict_issue(const Tile &T, int nd, const int32_t *far_tid, const double *theta, BlockDict &D) {
+    const int near_n = (int)T.near_n, far_n = nd - near_n, nb = (near_n + kBlk - 1) / kBlk;
+    const bool near_thread = (int)threadIdx.x < emsar::kDictBlocks;
 #pragma unroll
     for (int i = 0; i < kBlk; i++) {
-        const int d = (int)threadIdx.x * kBlk + i;
         D.th[i] = 0.0; D.tid[i] = -1;
-        if (threadIdx.x < emsar::kDictBlocks && d < nd) {
-            D.tid[i] = d < (int)T.near_n ? T.lo + d : __builtin_nontemporal_load(&far_tid[T.far_off + (d - (int)T.near_n)]);
-            if (MODE != MODE_SCATTER) D.th[i] = theta[D.tid[i]];
+        if (near_thread) {
+            const int d = (int)threadIdx.x * kBlk + i;
+            if ((int)threadIdx.x < nb && d < near_n) D.tid[i] = T.lo + d;
+        } else {
+            const int f = ((int)threadIdx.x - emsar::kDictBlocks) + i * (kTiledThreads - emsar::kDictBlocks);      // far entry: strided, coalesced
+            if (f < far_n) D.tid[i] = __builtin_nontemporal_load(&far_tid[T.far_off + f]);
         }
+        if (MODE != MODE_SCATTER && D.tid[i] >= 0) D.th[i] = theta[D.tid[i]];
     }
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int sl = (int)threadIdx.x + j * kTiledThreads;
-        D.stid[j] = sl < nd ? (sl < (int)T.near_n ? T.lo + sl : __builtin_nontemporal_load(&far_tid[T.far_off + (sl - (int)T.near_n)])) : -1;
+        D.stid[j] = sl < near_n ? T.lo + sl : -1;
     }
 }
-__device__ __forceinline__ void block_dict_store(const BlockDict &D, double *th_w, double *acc_w) {
+__device__ __forceinline__ void block_dict_store(const Tile &T, const BlockDict &D, double *th_w, double *acc_w) {
     constexpr int NE = emsar::kBlkEntries;
-    if (threadIdx.x < emsar::kDictBlocks) {
-        double *t = th_w + threadIdx.x * NE, *a = acc_w + threadIdx.x * NE;
-        double v[NE];
-        v[0] = 0.0;
+    const int nb = ((int)T.near_n + kBlk - 1) / kBlk;
+    if ((int)threadIdx.x < emsar::kDictBlocks) {
+        if ((int)threadIdx.x < nb) {
+            double *t = th_w + threadIdx.x * NE, *a = acc_w + threadIdx.x * NE;
+            double v[NE];
+            v[0] = 0.0;
 #pragma unroll
-        for (int m = 1; m < NE; m++) {                 // subset sum of m = that of m without its highest slot + theta of that slot
-            const int hi = 31 - __builtin_clz((unsigned)m);
-            v[m] = v[m & ~(1 << hi)] + D.th[hi];
+            for (int m = 1; m < NE; m++) {             // subset sum of m = that of m without its highest slot + theta of that slot
+                const int hi = 31 - __builtin_clz((unsigned)m);
+                v[m] = v[m & ~(1 << hi)] + D.th[hi];
+            }
+            const int sw = EMSAR_SWZ ? (int)(threadIdx.x & (NE - 1)) : 0;     // bank swizzle of the block (layout_tiled.hpp: entry_code)
+#pragma unroll
+            for (int m = 0; m < NE; m++) { t[m ^ sw] = v[m]; a[m] = 0.0; }
         }
-        const int sw = EMSAR_SWZ ? (int)(threadIdx.x & (NE - 1)) : 0;     // bank swizzle of the block (layout_tiled.hpp: entry_code)
+    } else {
 #pragma unroll
-        for (int m = 0; m < NE; m++) { t[m ^ sw] = v[m]; a[m] = 0.0; }
+        for (int i = 0; i < kBlk; i++) {
+            if (D.tid[i] < 0) continue;
+            const int e = NE * nb + ((int)threadIdx.x - emsar::kDictBlocks) + i * (kTiledThreads - emsar::kDictBlocks);
+            th_w[e] = D.th[i]; acc_w[e] = 0.0;
+        }
     }
 }
-// The flush is by SLOT, not by block: thread s (and s + 256) folds the subsets of its block that hold slot s and sends the sum to
-// its transcript -- consecutive lanes add to consecutive transcripts of the near range, 512 contiguous bytes per wave instruction
-// (device-scope float atomics run at full rate only on contiguous addresses; by block, a lane's three adds were 24 bytes apart).
-__device__ __forceinline__ void block_dict_flush(const BlockDict &D, const double *th_w, const double *acc_w, double *acc, double fx) {
+__device__ __forceinline__ void block_dict_flush(const Tile &T, const BlockDict &D, const double *th_w, const double *acc_w, double *acc, double fx) {
     constexpr int NE = emsar::kBlkEntries;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
@@ -187,6 +204,17 @@ __device__ __forceinline__ void block_dict_flush(const BlockDict &D, const doubl
 #pragma unroll
             for (int m = 1; m < NE; m++) if (m >> i & 1) si += a[m ^ sw];
             if (si != 0.0) atomic_add_f64(&acc[tid], si);
+        }
+    }
+    if ((int)threadIdx.x >= emsar::kDictBlocks) {      // the far entries this thread fetched: the accumulator IS the transcript's sum (its mass, in deterministic mode)
+        const int nb = ((int)T.near_n + kBlk - 1) / kBlk;
+#pragma unroll
+        for (int i = 0; i < kBlk; i++) {
+            if (D.tid[i] < 0) continue;
+            const int e = NE * nb + ((int)threadIdx.x - emsar::kDictBlocks) + i * (kTiledThreads - emsar::kDictBlocks);
+            const double v = acc_w[e];
+            if (fx != 0.0) { const long long iv = __double_as_longlong(v); if (iv != 0) atomic_add_i64(&acc[D.tid[i]], iv); }
+            else if (v != 0.0) atomic_add_f64(&acc[D.tid[i]], v);
         }
     }
 }
@@ -320,7 +348,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
         if (m > 0) load8_clamped(B, b, m < 8 ? m : 8);
     }
     // ---- phase 0: the table of subset sums into LDS, the accumulators cleared ----
-    block_dict_store(D, th_w, acc_w);
+    block_dict_store(T, D, th_w, acc_w);
     if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;      // padding row of this wave's slice
     if (STAMP) ts[1] = stamp_now();
     __syncthreads();
@@ -386,7 +414,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     __syncthreads();
     if (STAMP) ts[5] = stamp_now();
     // ---- F: the accumulators of every block folded into its transcripts and flushed ----
-    block_dict_flush(D, th_w, acc_w, acc, fx.mass);
+    block_dict_flush(T, D, th_w, acc_w, acc, fx.mass);
     if (STAMP && lane == 0) {   // [tile][wave][5 phases]: issue+dictionary, barrier, E, M, barrier
         for (int i = 0; i < 5; i++) stamps[((size_t)blockIdx.x * (kTiledThreads / 64) + wave) * 8 + i] = ts[i + 1] - ts[i];
     }
@@ -488,8 +516,7 @@ struct TileEnv {            // per-launch constants of the multi-tile kernel
 template <bool WEIGHTED, int MODE, int I, int N>
 __device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const Tile &T, const TileWave &W, int4 (&A)[8], int4 (&B)[8],
                                             BlockDict &D, double &ll) {
-    // a thread rewrites only the block it flushed at the end of the previous stage
-    block_dict_store(D, V.th_w, V.acc_w);
+    block_dict_store(T, D, V.th_w, V.acc_w);
     const BlockDict Dcur = D;                     // tids of THIS tile's block, for its flush; D is refilled for the next tile below
     const int in = it + V.stride;
     const bool has_next = (I + 1 < N) && in < V.n_tiles;
@@ -505,8 +532,9 @@ __device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const Tile
     if (W.has_slice) tile_m_step(W, B, V.coo, V.w_s, V.acc_w, V.lane, V.fx);
     if (has_next && Wn.has_slice && Wn.m > 0) load8_clamped(B, Wn.b, Wn.m < 8 ? Wn.m : 8);
     __syncthreads();
-    block_dict_flush(Dcur, V.th_w, V.acc_w, V.acc, V.fx);
+    block_dict_flush(T, Dcur, V.th_w, V.acc_w, V.acc, V.fx);
     if constexpr (I + 1 < N) {
+        if (has_next) __syncthreads();        // the flush reads by slot what the next stage's store writes by block: other threads
         if (has_next) tiled_stage<WEIGHTED, MODE, I + 1, N>(V, in, Tn, Wn, A, B, D, ll);
     }
 }
@@ -571,7 +599,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
         if (W.m > 0) load8_clamped(B, W.b, W.m < 8 ? W.m : 8);
     }
     if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;
-    block_dict_store(D, th_w, acc_w);
+    block_dict_store(T, D, th_w, acc_w);
     __syncthreads();
     double ll = 0.0;
     for (uint32_t t = t0; t < t1; t++) {              // the tiles of the unit, one after the other, on the same table
@@ -586,7 +614,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
         T = Tn; W = Wn;
     }
     __syncthreads();
-    block_dict_flush(D, th_w, acc_w, acc, fx.mass);
+    block_dict_flush(T, D, th_w, acc_w, acc, fx.mass);
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);
         if (threadIdx.x == 0 && t != 0.0) ll_add(ll_out, t, fx.ll);

@@ -8,7 +8,8 @@
 //   * rows with 2..kMaxRowLen tids are sorted by (block(anchor tid), class of their number of entries, anchor tid), anchor = median
 //     tid, and cut into TILES of at most 3072 rows whose distinct tids fit a 360-slot tile-local DICTIONARY: the contiguous range
 //     [lo, lo+near_n) that covers most of the tile's tids plus an explicit list of far tids.  The dictionary is organised in blocks
-//     of three slots and every stored operand is a 10-BIT ENTRY = block * 8 + subset (see kBlk below), three to a dword;
+//     of three slots and every stored operand is a 10-BIT ENTRY = block * 8 + subset (see kBlk below), three to a dword; a far
+//     tid has an entry of its own after the near blocks (kFarMax);
 //   * a tile has up to 4 SLICES of 768 rows; one wavefront owns one slice for the whole pass; two consecutive tiles may share a
 //     dictionary (a unit, Tile::follows):
 //       forward index (E-step, row sums): column-major [k][768]; lane l owns rows l, l+64, ..., so column j of its
@@ -63,6 +64,15 @@ constexpr int kDictBlocks = 960 / kBlkEntries;
 constexpr int kDictEntries = kDictBlocks * kBlkEntries;   // 960 doubles of LDS for T, 960 for the per-entry accumulators
 constexpr int kTileDict = kBlk * kDictBlocks;    // 360 transcripts per tile
 constexpr int64_t kFragRows = 1 << 21;   // sorted rows per independently tiled fragment (build_tiled)
+// Far transcripts (outside the tile's contiguous near range: cross-family hits, one or two rows each) do not get a slot of a block:
+// each has ONE table entry of its own after the near blocks (entry 8 nb + i names far transcript i; T = its theta).  A tile's
+// dictionary fits when 8 * ceil(near_n / 3) + far_n <= 960 and far_n <= kFarMax.
+constexpr int kFarMax = 3 * (256 - kDictBlocks);   // far entries are fetched and flushed by the threads that own no near block, 3 each
+constexpr int kTileDistinct = 700;               // distinct transcripts gathered before the dictionary is laid out (rows are given back if it does not fit)
+inline int near_blocks(int near_n) { return (near_n + kBlk - 1) / kBlk; }
+inline bool dict_fits(int64_t near_n, int64_t far_n) {
+    return far_n <= kFarMax && (int64_t)kBlkEntries * ((near_n + kBlk - 1) / kBlk) + far_n <= kDictEntries;
+}
 constexpr int kTileTids = kTileDict - (kBlk - 1);   // distinct transcripts of a tile: its near range starts at a multiple of kBlk, which may cost kBlk - 1 slots
 constexpr int kMaxRowLen = kTileTids;  // longer rows -> leftover CSR (a row must fit one dictionary)
 constexpr int kSegRows = 11;           // row ids per backward segment (plus 1 header = 12 x 10 bit = one int4)
@@ -85,12 +95,18 @@ constexpr int kDenseMin = 1;           // columns with fewer entries in a slice 
                                        // a load, an LDS read and an LDS atomic per entry -- costs more than a mostly empty segment: 4 / 2 / 1 -> 0.139 / 0.133 / 0.127 ms)
 // the entries (block * 8 + mask) of one row from its dictionary slots (any order; a slot that occurs twice -- an internal repeat
 // of the transcript -- opens a second entry of the same block: a subset holds a transcript once)
-inline void slots_to_entries(std::vector<uint32_t> &slots, std::vector<uint32_t> &ent) {
+inline void slots_to_entries(std::vector<uint32_t> &slots, std::vector<uint32_t> &ent, uint32_t near_n) {
     std::sort(slots.begin(), slots.end());
     ent.clear();
     int cur_b = -1;
     uint32_t cur_m = 0;
+    const uint32_t far_base = (uint32_t)kBlkEntries * (uint32_t)near_blocks((int)near_n);
     for (uint32_t sl : slots) {
+        if (sl >= near_n) {                       // a far transcript: its own entry (slots are sorted: the far ones come last)
+            if (cur_b >= 0) { ent.push_back(entry_code((uint32_t)cur_b, cur_m)); cur_b = -1; cur_m = 0; }
+            ent.push_back(far_base + (sl - near_n));
+            continue;
+        }
         const int b = (int)(sl / (uint32_t)kBlk);
         const uint32_t bit = 1u << (sl % (uint32_t)kBlk);
         if (b != cur_b || (cur_m & bit)) {
@@ -184,7 +200,7 @@ inline int check_tiled_extents(const TiledLayout &L) {
     std::vector<uint8_t> slice_used(nslot / (size_t)kTileSliceRows, 0);
     for (const Tile &T : L.tiles) {
         const int nd = (int)T.near_n + (int)T.far_n;
-        if (T.n_slices < 1 || T.n_slices > kTileSlices || nd > kTileDict) return -22;
+        if (T.n_slices < 1 || T.n_slices > kTileSlices || T.near_n < 1 || !dict_fits(T.near_n, T.far_n)) return -22;
         if (T.lo < 0 || (int64_t)T.lo + T.near_n > (int64_t)L.n_tx) return -23;
         if ((size_t)T.far_off + T.far_n > nfar) return -24;
         if (T.row_base % (uint32_t)kTileSliceRows || (size_t)T.row_base + (size_t)T.n_slices * kTileSliceRows > nslot) return -25;
@@ -199,12 +215,14 @@ inline int check_tiled_extents(const TiledLayout &L) {
             const size_t fw = (size_t)T.k[s] * kSliceDwords, bw = (size_t)T.m[s] * 64 * 4;
             if (foff + fw > nf || boff + bw > nb || coff + T.coo_n[s] > nc) return -28;
             // an entry names a block and a subset of it: every slot of the subset must exist in the tile's dictionary
+            const uint32_t far_base = (uint32_t)kBlkEntries * (uint32_t)near_blocks(T.near_n);
             auto entry_ok = [&](uint32_t e) {
-                if (e >= (uint32_t)kDictEntries) return false;
+                if (e >= far_base) return e - far_base < (uint32_t)T.far_n;        // a far transcript's own entry
                 const uint32_t m = entry_mask(e), b = e >> kBlk;
-                for (int i = 0; i < kBlk; i++) if ((m >> i & 1u) && b * (uint32_t)kBlk + (uint32_t)i >= (uint32_t)nd) return false;
+                for (int i = 0; i < kBlk; i++) if ((m >> i & 1u) && b * (uint32_t)kBlk + (uint32_t)i >= (uint32_t)T.near_n) return false;
                 return true;
             };
+            auto entry_empty = [&](uint32_t e) { return e < far_base && entry_mask(e) == 0; };
             for (size_t i = 0; i < fw; i++) {
                 const uint32_t d = L.fwd[foff + i];
                 if (!entry_ok(d & 0x3FFu) || !entry_ok((d >> 10) & 0x3FFu) || !entry_ok((d >> 20) & 0x3FFu)) return -29;
@@ -214,11 +232,11 @@ inline int check_tiled_extents(const TiledLayout &L) {
                 bool any = false;
                 for (int w = 1; w < 12; w++) { const uint32_t rl = unpack10(q, w); if (rl > (uint32_t)kTileSliceRows) return -29; any |= rl != (uint32_t)kTileSliceRows; }
                 const uint32_t e = unpack10(q, 0);
-                if (!entry_ok(e) || (any && entry_mask(e) == 0)) return -29;
+                if (!entry_ok(e) || (any && entry_empty(e))) return -29;
             }
             for (size_t i = 0; i < T.coo_n[s]; i++) {
                 const uint32_t p = L.coo[coff + i];
-                if (!entry_ok(p >> 16) || entry_mask(p >> 16) == 0 || (p & 0xFFFFu) >= (uint32_t)kTileSliceRows) return -29;
+                if (!entry_ok(p >> 16) || entry_empty(p >> 16) || (p & 0xFFFFu) >= (uint32_t)kTileSliceRows) return -29;
             }
             foff += fw; boff += bw; coff += T.coo_n[s];
         }
@@ -479,7 +497,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                     int32_t t = col_idx[k];
                     if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
                 }
-                if (i1 > i0 && (int64_t)distinct.size() > kTileTids) {   // undo this row, close the tile
+                if (i1 > i0 && (int64_t)distinct.size() > kTileDistinct) {   // undo this row, close the tile
                     for (size_t q = before; q < distinct.size(); q++) stamp[(size_t)distinct[q]] = -1;
                     distinct.resize(before);
                     break;
@@ -487,7 +505,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 ents += (int64_t)(e - b);
                 i1++;
             }
-            if ((int64_t)distinct.size() > kTileTids) return -3;       // a single row with too many tids: excluded by kMaxRowLen
+            if ((int64_t)distinct.size() > kTileDistinct) return -3;   // a single row with too many tids: excluded by kMaxRowLen
             // a tile closed by the dictionary or entry cap in the middle of a slice would pad that slice with empty rows
             // (forward bytes and gathers for nothing): give the rows of the started slice to the next tile instead
             if (cut_at_slices && i1 < n_act && i1 - i0 > kTileSliceRows && (i1 - i0) % kTileSliceRows != 0) {
@@ -503,15 +521,39 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                     }
                 }
             }
-            // 2. dictionary: the contiguous tid range [distinct[a], distinct[c]] that covers the MOST of the tile's
-            //    tids while (range length + tids outside it) still fits; the tids outside (cross-family hits on
-            //    either side) go to the explicit far list.  slots(a,c) = n + (tids missing inside the range).
-            std::sort(distinct.begin(), distinct.end());
-            const size_t n = distinct.size();
-            size_t best_a = 0, best_c = 0, a = 0;
-            for (size_t c = 0; c < n; c++) {
-                while ((int64_t)n + ((int64_t)distinct[c] - distinct[a]) - (int64_t)(c - a) + (kBlk - 1) > kTileDict) a++;
-                if (c == 0 || c - a > best_c - best_a) { best_a = a; best_c = c; }
+            // 2. dictionary: the contiguous tid range [distinct[a], distinct[c]] that covers the MOST of the tile's tids while the
+            //    near blocks (8 table entries per 3 slots of the range, tids present or not) plus one entry per tid outside the range
+            //    (cross-family hits on either side: the far list) still fit the table.  The cost falls as a grows and rises as c grows,
+            //    so the smallest feasible a for every c gives the widest cover.  If not even the best window fits, the unit gives
+            //    back its last slice of rows and tries again.
+            size_t best_a = 0, best_c = 0;
+            for (;;) {
+                std::sort(distinct.begin(), distinct.end());
+                const size_t n = distinct.size();
+                size_t a = 0;
+                bool any = false;
+                for (size_t c = 0; c < n; c++) {
+                    auto fits = [&](size_t aa) {
+                        const int64_t lo_a = distinct[aa] - distinct[aa] % kBlk;
+                        return dict_fits((int64_t)distinct[c] - lo_a + 1, (int64_t)n - (int64_t)(c - aa + 1));
+                    };
+                    while (a < c && !fits(a)) a++;
+                    if (!fits(a)) continue;
+                    if (!any || c - a > best_c - best_a) { best_a = a; best_c = c; any = true; }
+                }
+                if (any) break;
+                if (i1 - i0 <= 1) return -3;
+                const int64_t keep = i1 - i0 > kTileSliceRows ? (i1 - i0 - 1) / kTileSliceRows * kTileSliceRows : (i1 - i0) / 2;
+                for (int32_t t : distinct) stamp[(size_t)t] = -1;
+                distinct.clear();
+                i1 = i0 + std::max<int64_t>(keep, 1);
+                for (int64_t i = i0; i < i1; i++) {
+                    uint32_t r = perm[(size_t)i];
+                    for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+                        int32_t t = col_idx[k];
+                        if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
+                    }
+                }
             }
             const int32_t lo = distinct[best_a] - distinct[best_a] % kBlk;       // blocks of the near range = tid / kBlk (see ecnt)
             const int32_t near_n = distinct[best_c] - lo + 1;
@@ -539,7 +581,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                     rslots.push_back((uint32_t)d);
                     if (d >= near_n) out.far_entries++;
                 }
-                slots_to_entries(rslots, rents);
+                slots_to_entries(rslots, rents, (uint32_t)near_n);
                 rent.insert(rent.end(), rents.begin(), rents.end());
                 rent_ptr.push_back((uint32_t)rent.size());
                 out.tiled_entries += (int64_t)rents.size();
@@ -754,7 +796,8 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
     std::vector<uint32_t> pf, pb;
     for (const Tile &T : L.tiles) {
         const int nd = T.near_n + T.far_n;
-        if (nd > kTileDict || T.n_slices > kTileSlices || T.row_base % kTileSliceRows) return -3;
+        if (!dict_fits(T.near_n, T.far_n) || T.n_slices > kTileSlices || T.row_base % kTileSliceRows) return -3;
+        const uint32_t far_base = (uint32_t)kBlkEntries * (uint32_t)near_blocks(T.near_n);
         auto tid_of = [&](int d) { return d < T.near_n ? T.lo + d : L.far_tid[(size_t)T.far_off + (size_t)(d - T.near_n)]; };
         size_t foff = (size_t)(T.fwd_off / 4), boff = (size_t)(T.bwd_off / 4), coff = T.coo_off;
         for (int s = 0; s < T.n_slices; s++) {
@@ -765,10 +808,13 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
                 for (int j = 0; j < T.k[s]; j++) {
                     const int fl = i & 63, fi = i >> 6;
                     const uint32_t e = (L.fwd[foff + (size_t)j * kSliceDwords + (size_t)(fl * 4 + fi / 3)] >> (10 * (fi % 3))) & 0x3FFu;
-                    const uint32_t msk = entry_mask(e);
-                    if (msk == 0) { if (e != 0) return -4; continue; }   // entry 0 = padding
-                    for (int bit = 0; bit < kBlk; bit++)
-                        if (msk >> bit & 1u) a.push_back(tid_of((int)(e >> kBlk) * kBlk + bit));
+                    if (e >= far_base) a.push_back(tid_of((int)T.near_n + (int)(e - far_base)));
+                    else {
+                        const uint32_t msk = entry_mask(e);
+                        if (msk == 0) { if (e != 0) return -4; continue; }   // entry 0 = padding
+                        for (int bit = 0; bit < kBlk; bit++)
+                            if (msk >> bit & 1u) a.push_back(tid_of((int)(e >> kBlk) * kBlk + bit));
+                    }
                     pf.push_back((e << 16) | (uint32_t)i);
                 }
                 if (r < 0) { if (!a.empty()) return -5; continue; }
@@ -800,7 +846,7 @@ inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int3
                 for (int w = 1; w < 12; w++) {
                     uint32_t rl = unpack10(q, w);
                     if (rl == (uint32_t)kTileSliceRows) continue;
-                    if (rl > (uint32_t)kTileSliceRows || d >= (uint32_t)kDictEntries || entry_mask(d) == 0) return -8;
+                    if (rl > (uint32_t)kTileSliceRows || d >= (uint32_t)kDictEntries || (d < far_base && entry_mask(d) == 0)) return -8;
                     pb.push_back((d << 16) | rl);
                 }
             }
