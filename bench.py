@@ -124,7 +124,7 @@ def main():
     out = None
     if rank == 0:
         per_pass_s = kernel_ms / 1e3 / args.steps
-        tiled_kernel = "k_pass_tiled_unit"      # above 2048 tiles (below: k_pass_tiled, one tile per workgroup)
+        tiled_kernel = "k_pass_tiled_unit" if info["n_chunks"] > 2048 else "k_pass_tiled"     # units of two tiles above 2048 tiles, one tile per workgroup below
         bytes_pass = info["bytes_per_pass"]
         achieved = bytes_pass / per_pass_s / 1e9
         out = {
