@@ -1076,6 +1076,34 @@ int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
     return EMSAR_HIP_OK;
 }
 
+// The same for the unit kernel (the one config 3 runs): out[0..5] = mean cycles per wave in: descriptor + dictionary + first loads,
+// barrier, E-steps, M-steps, barrier, flush; out[6] = tiles per unit; out[7] = units.
+int emsar_hip_debug_unit_stamps(emsar_hip_ctx *ctx, double *out) {
+    if (!ctx || !out || ctx->layout != EMSAR_LAYOUT_TILED || !ctx->have_sample || ctx->weighted || ctx->n_units == 0) return EMSAR_HIP_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    const size_t nw = (size_t)ctx->n_units * (kTiledThreads / 64), bytes = nw * 8 * sizeof(unsigned long long);
+    HIPCHK(hipMalloc(&d, bytes));
+    HIPCHK(hipMemsetAsync(d, 0, bytes, ctx->stream));
+    const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
+    HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_unit<false, MODE_EM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_pass_tiled_unit<false, MODE_EM, true>), dim3((unsigned)ctx->n_units), dim3(kTiledThreads), lds, ctx->stream, ctx->d_tiles, ctx->d_units,
+                       ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].s[0].v, Fx{0.0, 0.0}, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
+    std::vector<unsigned long long> h(nw * 8);
+    HIPCHK(hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dfree(d);
+    for (int i = 0; i < 7; i++) {
+        double sum = 0;
+        for (size_t w = 0; w < nw; w++) sum += (double)h[w * 8 + (size_t)i];
+        out[i] = sum / (double)nw;
+    }
+    out[7] = (double)ctx->n_units;
+    return EMSAR_HIP_OK;
+}
+
 int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                                      int merge_rows, emsar_hip_info *info_out) {
     try {

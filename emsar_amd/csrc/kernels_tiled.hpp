@@ -23,6 +23,9 @@ namespace {
 #ifndef EMSAR_UE_BATCH          // LDS gathers in flight per step of the E / M loops of the unit and multi kernels (tile_e_step,
 #define EMSAR_UE_BATCH 6        // tile_m_step); 6 / 12 in any combination measured 0.1159 - 0.1165 ms: no difference
 #endif
+#ifndef EMSAR_UNIT_MIRROR       // 1: the waves take the slices of every other tile of a unit in reverse order (k_pass_tiled_unit)
+#define EMSAR_UNIT_MIRROR 1
+#endif
 #ifndef EMSAR_UM_BATCH
 #define EMSAR_UM_BATCH 6
 #endif
@@ -577,20 +580,26 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Til
 // barrier ... barrier -> flush) had grown to 44 % of a wave's life in barrier waits: a unit pays it once for up to eight slices.
 // Tile 2's forward columns are requested while tile 1's M-step runs, its backward segments afterwards (as in k_pass_tiled_multi).
 // ------------------------------------------------------------------------------------------------
-template <bool WEIGHTED, int MODE>
+template <bool WEIGHTED, int MODE, bool STAMP = false>
 __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile *__restrict__ tiles, const uint32_t *__restrict__ unit_first,
                                                                    const uint32_t *__restrict__ fwd, const uint32_t *__restrict__ bwd,
                                                                    const uint32_t *__restrict__ coo, const int32_t *__restrict__ far_tid,
                                                                    const int32_t *__restrict__ wgt, const double *__restrict__ theta,
-                                                                   double *__restrict__ acc, double *__restrict__ ll_out, Fx fx) {
+                                                                   double *__restrict__ acc, double *__restrict__ ll_out, Fx fx,
+                                                                   unsigned long long *stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double red[kTiledThreads / 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *th_w = lds, *acc_w = lds + kTiledDictPad, *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, te = 0, tm = 0;      // STAMP: shader-clock stamps of the phases (diagnostic instance only)
+    if (STAMP) ts0 = stamp_now();
     const uint32_t t0 = unit_first[blockIdx.x], t1 = unit_first[blockIdx.x + 1];
     Tile T = tiles[t0];
-    TileWave W = tile_wave(T, wave, lane, fwd, bwd);
+    // The slices of a unit are in descending order of work (layout_tiled.hpp); wave w takes slice w of the unit's first and third
+    // tile and slice 3 - w of the second and fourth: the wave with the longest slice of one tile has the shortest of the next.
+    int slice = wave;
+    TileWave W = tile_wave(T, slice, lane, fwd, bwd);
     BlockDict D;
     int4 A[8], B[8];
     block_dict_issue<MODE>(T, W.nd, far_tid, theta, D);
@@ -600,21 +609,35 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     }
     if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;
     block_dict_store(T, D, th_w, acc_w);
+    if (STAMP) ts1 = stamp_now();
     __syncthreads();
+    if (STAMP) ts2 = stamp_now();
     double ll = 0.0;
-    for (uint32_t t = t0; t < t1; t++) {              // the tiles of the unit, one after the other, on the same table
-        if (W.has_slice) tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)wave * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
+    for (uint32_t t = t0; t < t1; t++) {
+        unsigned long long ta = 0, tb = 0;
+        if (STAMP) ta = stamp_now();              // the tiles of the unit, one after the other, on the same table
+        if (W.has_slice) tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)slice * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
         const bool more = t + 1 < t1;
         const Tile Tn = tiles[more ? t + 1 : t];
-        TileWave Wn = tile_wave(Tn, wave, lane, fwd, bwd);
+        slice = EMSAR_UNIT_MIRROR ? emsar::kTileSlices - 1 - slice : slice;
+        TileWave Wn = tile_wave(Tn, slice, lane, fwd, bwd);
         if (!more) Wn.has_slice = false;
+        if (STAMP) tb = stamp_now();
         if (Wn.has_slice) load8_clamped(A, Wn.e, Wn.k < 8 ? Wn.k : 8);        // the next tile's forward columns during this one's M-step
         if (W.has_slice) tile_m_step(W, B, coo, w_s, acc_w, lane, fx.mass);
+        if (STAMP) { const unsigned long long tc = stamp_now(); te += tb - ta; tm += tc - tb; }
         if (Wn.has_slice && Wn.m > 0) load8_clamped(B, Wn.b, Wn.m < 8 ? Wn.m : 8);
         T = Tn; W = Wn;
     }
+    unsigned long long ts3 = 0, ts4 = 0;
+    if (STAMP) ts3 = stamp_now();
     __syncthreads();
+    if (STAMP) ts4 = stamp_now();
     block_dict_flush(T, D, th_w, acc_w, acc, fx.mass);
+    if (STAMP && lane == 0) {      // [unit][wave]: descriptor + dictionary + first loads, barrier, E-steps, M-steps, barrier, flush, tiles
+        unsigned long long *o = stamps + ((size_t)blockIdx.x * (kTiledThreads / 64) + wave) * 8;
+        o[0] = ts1 - ts0; o[1] = ts2 - ts1; o[2] = te; o[3] = tm; o[4] = ts4 - ts3; o[5] = stamp_now() - ts4; o[6] = t1 - t0; o[7] = ts3 - ts2 - te - tm;
+    }
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);
         if (threadIdx.x == 0 && t != 0.0) ll_add(ll_out, t, fx.ll);

@@ -430,6 +430,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     const int64_t unit_rows = tile_rows * unit_tiles;
     int dense_min = kDenseMin;
     if (const char *e = getenv("EMSAR_HIP_TILE_DENSE")) { int v = atoi(e); if (v >= 1 && v <= 64) dense_min = v; }
+    bool unit_sort = true;
+    if (const char *e = getenv("EMSAR_HIP_UNIT_SORT")) unit_sort = atoi(e) != 0;
     bool cut_at_slices = true;
     if (const char *e = getenv("EMSAR_HIP_TILE_CUT")) cut_at_slices = atoi(e) != 0;
     const auto tp1 = t_now();
@@ -480,6 +482,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         std::vector<uint32_t> pairs, sorted;   // (col_local << 16) | row_in_slice
         std::vector<uint32_t> ccount, fill;
         std::vector<uint32_t> segs;            // 4 dwords per segment
+        std::vector<uint32_t> uord;            // the unit's rows in the order they are laid out
         std::vector<uint32_t> rslots, rents, rent, rent_ptr;   // one row's slots / entries; all rows' entries of the tile
         int64_t i0 = range_begin;
         int32_t tile_id = 0;
@@ -571,10 +574,15 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             const int nd = near_n + far_n;
             const uint32_t pad_row = (uint32_t)kTileSliceRows;             // w_r[768] of every slice = 0
             const Tile Tdict = T;                                          // what the tiles of the unit share: the dictionary
+            // The rows of the unit in descending order of their entry count (stable: rows of one count keep the order of the
+            // sort above).  A slice's forward width is its longest row, so slices of equal rows carry the least padding, and
+            // the slices come out in descending order of work -- what the unit kernel's wave assignment expects.
+            uord.assign(perm.begin() + i0, perm.begin() + i1);
+            if (unit_sort) std::stable_sort(uord.begin(), uord.end(), [&](uint32_t a, uint32_t b) { return ecnt[a] > ecnt[b]; });
             // the entries of every row of the tile, once (used by the forward and by the backward index)
             rent_ptr.assign(1, 0u); rent.clear();
             for (int64_t i = i0; i < i1; i++) {
-                const uint32_t r = perm[(size_t)i];
+                const uint32_t r = uord[(size_t)(i - i0)];
                 rslots.clear();
                 for (uint64_t q = row_ptr[r]; q < row_ptr[r + 1]; q++) {
                     const int32_t d = loc[(size_t)col_idx[q]];
@@ -611,7 +619,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 out.fwd.resize(base + (size_t)k * kSliceDwords, 0u);            // entry 0 = the empty subset: padding
                 out.padded_slots += k * kTileSliceRows;
                 for (int64_t i = a0; i < bnd; i++) {
-                    uint32_t r = perm[(size_t)i];
+                    uint32_t r = uord[(size_t)(i - i0)];
                     uint32_t in_slice = (uint32_t)(i - a0);
                     out.slot_row[(size_t)T.row_base + (size_t)s * kTileSliceRows + in_slice] = (int64_t)r;
                     const uint32_t b = rent_ptr[(size_t)(i - i0)], e = rent_ptr[(size_t)(i - i0) + 1];

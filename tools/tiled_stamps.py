@@ -19,3 +19,11 @@ print("rc", rc, "tiles", out[7], "mean cycles per wave", tot)
 for i, n in enumerate(names):
     print("%-26s %10.0f  %5.1f%%" % (n, out[i], 100 * out[i] / tot))
 print("ms/pass (unstamped)", dev.run_passes(20) / 20)
+out = (C.c_double * 8)()
+dev._L.emsar_hip_debug_unit_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+rc = dev._L.emsar_hip_debug_unit_stamps(dev._h, out)
+names = ["descriptor + dictionary + loads", "barrier 1", "E-steps", "M-steps", "barrier 2", "flush"]
+tot = sum(out[i] for i in range(6))
+print("unit kernel: rc", rc, "units", out[7], "tiles per unit %.2f" % out[6], "mean cycles per wave", tot)
+for i, n in enumerate(names):
+    print("%-34s %10.0f  %5.1f%%" % (n, out[i], 100 * out[i] / tot))
