@@ -133,17 +133,27 @@ struct BlockDict { double th[kBlk]; int tid[kBlk]; int stid[2]; };     // stid: 
 constexpr int kSlotsPerThread = (emsar::kTileDict + kTiledThreads - 1) / kTiledThreads;
 static_assert(kSlotsPerThread == 2, "BlockDict::stid");
 static_assert(emsar::kFarMax == kBlk * (kTiledThreads - emsar::kDictBlocks), "three far entries per thread that owns no near block");
-template <int MODE>
+// the far list of a unit from its fixed-stride copy (layout_tiled.hpp: UnitTables): needs no descriptor
+__device__ __forceinline__ void block_dict_far_issue(const int32_t *ufar, int far_stride, BlockDict &D) {
+#pragma unroll
+    for (int i = 0; i < kBlk; i++) {
+        D.tid[i] = -1;
+        const int f = ((int)threadIdx.x - emsar::kDictBlocks) + i * (kTiledThreads - emsar::kDictBlocks);
+        if ((int)threadIdx.x >= emsar::kDictBlocks && f < far_stride) D.tid[i] = __builtin_nontemporal_load(&ufar[f]);
+    }
+}
+template <int MODE, bool FAR_ISSUED = false>
 __device__ __forceinline__ void block_dict_issue(const Tile &T, int nd, const int32_t *far_tid, const double *theta, BlockDict &D) {
     const int near_n = (int)T.near_n, far_n = nd - near_n, nb = (near_n + kBlk - 1) / kBlk;
     const bool near_thread = (int)threadIdx.x < emsar::kDictBlocks;
 #pragma unroll
     for (int i = 0; i < kBlk; i++) {
-        D.th[i] = 0.0; D.tid[i] = -1;
+        D.th[i] = 0.0;
+        if (!FAR_ISSUED || near_thread) D.tid[i] = -1;
         if (near_thread) {
             const int d = (int)threadIdx.x * kBlk + i;
             if ((int)threadIdx.x < nb && d < near_n) D.tid[i] = T.lo + d;
-        } else {
+        } else if (!FAR_ISSUED) {
             const int f = ((int)threadIdx.x - emsar::kDictBlocks) + i * (kTiledThreads - emsar::kDictBlocks);      // far entry: strided, coalesced
             if (f < far_n) D.tid[i] = __builtin_nontemporal_load(&far_tid[T.far_off + f]);
         }
@@ -581,9 +591,9 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Til
 // Tile 2's forward columns are requested while tile 1's M-step runs, its backward segments afterwards (as in k_pass_tiled_multi).
 // ------------------------------------------------------------------------------------------------
 template <bool WEIGHTED, int MODE, bool STAMP = false>
-__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile *__restrict__ tiles, const uint32_t *__restrict__ unit_first,
+__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile *__restrict__ utiles, int stride, const int32_t *__restrict__ ufar, int far_stride,
                                                                    const uint32_t *__restrict__ fwd, const uint32_t *__restrict__ bwd,
-                                                                   const uint32_t *__restrict__ coo, const int32_t *__restrict__ far_tid,
+                                                                   const uint32_t *__restrict__ coo,
                                                                    const int32_t *__restrict__ wgt, const double *__restrict__ theta,
                                                                    double *__restrict__ acc, double *__restrict__ ll_out, Fx fx,
                                                                    unsigned long long *stamps = nullptr) {
@@ -594,15 +604,17 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     double *th_w = lds, *acc_w = lds + kTiledDictPad, *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, te = 0, tm = 0;      // STAMP: shader-clock stamps of the phases (diagnostic instance only)
     if (STAMP) ts0 = stamp_now();
-    const uint32_t t0 = unit_first[blockIdx.x], t1 = unit_first[blockIdx.x + 1];
-    Tile T = tiles[t0];
+    const Tile *tiles = utiles + (size_t)blockIdx.x * (size_t)stride;          // the unit's tiles and far list: addresses known from the start
+    BlockDict D;
+    block_dict_far_issue(ufar + (size_t)blockIdx.x * (size_t)far_stride, far_stride, D);
+    Tile T = tiles[0];
+    const int dict_near_n = (int)T.near_n;                                       // the dictionary is the unit's, not the tile's
     // The slices of a unit are in descending order of work (layout_tiled.hpp); wave w takes slice w of the unit's first and third
     // tile and slice 3 - w of the second and fourth: the wave with the longest slice of one tile has the shortest of the next.
     int slice = wave;
     TileWave W = tile_wave(T, slice, lane, fwd, bwd);
-    BlockDict D;
     int4 A[8], B[8];
-    block_dict_issue<MODE>(T, W.nd, far_tid, theta, D);
+    block_dict_issue<MODE, true>(T, W.nd, nullptr, theta, D);
     if (W.has_slice) {
         load8_clamped(A, W.e, W.k < 8 ? W.k : 8);
         if (W.m > 0) load8_clamped(B, W.b, W.m < 8 ? W.m : 8);
@@ -613,12 +625,13 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     __syncthreads();
     if (STAMP) ts2 = stamp_now();
     double ll = 0.0;
-    for (uint32_t t = t0; t < t1; t++) {
+    int n_done = 0;
+    for (int t = 0;; t++) {
         unsigned long long ta = 0, tb = 0;
         if (STAMP) ta = stamp_now();              // the tiles of the unit, one after the other, on the same table
         if (W.has_slice) tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)slice * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
-        const bool more = t + 1 < t1;
-        const Tile Tn = tiles[more ? t + 1 : t];
+        const Tile Tn = tiles[t + 1 < stride ? t + 1 : t];
+        const bool more = t + 1 < stride && Tn.n_slices > 0;
         slice = EMSAR_UNIT_MIRROR ? emsar::kTileSlices - 1 - slice : slice;
         TileWave Wn = tile_wave(Tn, slice, lane, fwd, bwd);
         if (!more) Wn.has_slice = false;
@@ -628,15 +641,18 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
         if (STAMP) { const unsigned long long tc = stamp_now(); te += tb - ta; tm += tc - tb; }
         if (Wn.has_slice && Wn.m > 0) load8_clamped(B, Wn.b, Wn.m < 8 ? Wn.m : 8);
         T = Tn; W = Wn;
+        n_done = t + 1;
+        if (!more) break;
     }
     unsigned long long ts3 = 0, ts4 = 0;
     if (STAMP) ts3 = stamp_now();
     __syncthreads();
     if (STAMP) ts4 = stamp_now();
+    T.near_n = (uint16_t)dict_near_n;            // (T is the last tile read by now: an absent one when the unit has fewer tiles than the stride)
     block_dict_flush(T, D, th_w, acc_w, acc, fx.mass);
     if (STAMP && lane == 0) {      // [unit][wave]: descriptor + dictionary + first loads, barrier, E-steps, M-steps, barrier, flush, tiles
         unsigned long long *o = stamps + ((size_t)blockIdx.x * (kTiledThreads / 64) + wave) * 8;
-        o[0] = ts1 - ts0; o[1] = ts2 - ts1; o[2] = te; o[3] = tm; o[4] = ts4 - ts3; o[5] = stamp_now() - ts4; o[6] = t1 - t0; o[7] = ts3 - ts2 - te - tm;
+        o[0] = ts1 - ts0; o[1] = ts2 - ts1; o[2] = te; o[3] = tm; o[4] = ts4 - ts3; o[5] = stamp_now() - ts4; o[6] = n_done; o[7] = ts3 - ts2 - te - tm;
     }
     if (MODE == MODE_EM_LL) {
         double t = block_sum<kTiledThreads>(ll, red);

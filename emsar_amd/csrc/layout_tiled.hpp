@@ -782,6 +782,31 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     return ext == 0 ? 0 : ext;
 }
 
+// What k_pass_tiled_unit reads first, at addresses that depend on the workgroup index alone (nothing to chase: the descriptor and
+// the far list are requested together, the theta gather is the second memory round trip of a workgroup, not the fourth):
+//   utiles[u * stride + j]   the j-th tile of unit u, j < stride = the most tiles any unit has; absent tiles have n_slices = 0
+//   ufar[u * far_stride + f] the unit's f-th far transcript, -1 beyond its far_n; far_stride = the longest far list, rounded up to 8
+struct UnitTables { std::vector<Tile> utiles; std::vector<int32_t> ufar; int stride = 1, far_stride = 8; };
+inline void build_unit_tables(const TiledLayout &L, UnitTables &U) {
+    const size_t nu = L.unit_first.empty() ? 0 : L.unit_first.size() - 1;
+    int stride = 1, far_max = 0;
+    for (size_t u = 0; u < nu; u++) {
+        stride = std::max(stride, (int)(L.unit_first[u + 1] - L.unit_first[u]));
+        far_max = std::max(far_max, (int)L.tiles[L.unit_first[u]].far_n);
+    }
+    U.stride = stride; U.far_stride = std::max(8, (far_max + 7) / 8 * 8);
+    Tile none;
+    std::memset(&none, 0, sizeof none);
+    U.utiles.assign(nu * (size_t)stride, none);
+    U.ufar.assign(nu * (size_t)U.far_stride, -1);
+    for (size_t u = 0; u < nu; u++) {
+        const uint32_t a = L.unit_first[u], b = L.unit_first[u + 1];
+        for (uint32_t t = a; t < b; t++) U.utiles[u * (size_t)stride + (t - a)] = L.tiles[t];
+        const Tile &T = L.tiles[a];
+        for (uint32_t f = 0; f < T.far_n; f++) U.ufar[u * (size_t)U.far_stride + f] = L.far_tid[(size_t)T.far_off + f];
+    }
+}
+
 // Decode and compare with the input (host self-check, used by the CPU tests). 0 = identical.
 inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int32_t *col_idx) {
     if (const int ext = check_tiled_extents(L)) return ext;          // the decode below indexes the arrays by the descriptors
