@@ -93,7 +93,7 @@ struct emsar_hip_ctx {
     bool det = false;            // deterministic mode (emsar_hip_set_deterministic / EMSAR_HIP_DETERMINISTIC): fixed-point sums, kernels_common.hpp
     double fx_mass = 0.0, fx_ll = 0.0;   // its scales for the current sample (upload_sample)
     double *d_sqpart = nullptr;  // per-workgroup partial sums of the SQUAREM vector kernels [4][kSqPart]
-    int update_grid = 256;       // workgroups of k_update (EMSAR_HIP_UPDATE_GRID)
+    int update_grid = 1024;       // workgroups of k_update (EMSAR_HIP_UPDATE_GRID)
     int sq_grid = 256;           // workgroups of the SQUAREM vector kernels (EMSAR_HIP_SQ_GRID)
     int tiled_multi = 1;         // EMSAR_HIP_TILED_MULTI 1: two tiles per workgroup (k_pass_tiled_multi) above kPairMinTiles tiles, else one
                                  // (k_pass_tiled); 2: always two; 0: always one
@@ -1087,11 +1087,11 @@ int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
 
 // The same for the unit kernel (the one config 3 runs): out[0..5] = mean cycles per wave in: descriptor + dictionary + first loads,
 // barrier, E-steps, M-steps, barrier, flush; out[6] = tiles per unit; out[7] = units.
-int emsar_hip_debug_unit_stamps(emsar_hip_ctx *ctx, double *out) {
+int emsar_hip_debug_unit_stamps(emsar_hip_ctx *ctx, double *out, unsigned long long *timeline /* NULL or 4 words per unit: start, end (100 MHz ticks), place, tiles */) {
     if (!ctx || !out || ctx->layout != EMSAR_LAYOUT_TILED || !ctx->have_sample || ctx->weighted || ctx->n_units == 0) return EMSAR_HIP_ERR_STATE;
     HIPCHK(hipSetDevice(ctx->device));
     unsigned long long *d = nullptr;
-    const size_t nw = (size_t)ctx->n_units * (kTiledThreads / 64), bytes = nw * 8 * sizeof(unsigned long long);
+    const size_t nw = (size_t)ctx->n_units * (kTiledThreads / 64), bytes = (nw * 8 + (size_t)ctx->n_units * 4) * sizeof(unsigned long long);
     HIPCHK(hipMalloc(&d, bytes));
     HIPCHK(hipMemsetAsync(d, 0, bytes, ctx->stream));
     const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
@@ -1100,10 +1100,11 @@ int emsar_hip_debug_unit_stamps(emsar_hip_ctx *ctx, double *out) {
                        ctx->d_ufar, ctx->far_stride, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_wgt, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].s[0].v, Fx{0.0, 0.0}, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
-    std::vector<unsigned long long> h(nw * 8);
+    std::vector<unsigned long long> h(nw * 8 + (size_t)ctx->n_units * 4);
     HIPCHK(hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dfree(d);
+    if (timeline) std::copy(h.begin() + (std::ptrdiff_t)(nw * 8), h.end(), timeline);
     for (int i = 0; i < 7; i++) {
         double sum = 0;
         for (size_t w = 0; w < nw; w++) sum += (double)h[w * 8 + (size_t)i];
@@ -1120,6 +1121,7 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
         emsar::TiledLayout L;
         if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows != 0) != 0) return EMSAR_HIP_ERR_ARG;
         int rc = emsar::check_tiled(L, row_ptr, col_idx);
+        { emsar::UnitTables U; emsar::build_unit_tables(L, U); }       // (debug statistics; the tables are checked by the GPU parity tests)
         if (info_out) {
             memset(info_out, 0, sizeof(*info_out));
             info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx;

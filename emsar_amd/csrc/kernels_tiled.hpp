@@ -219,17 +219,19 @@ __device__ __forceinline__ void block_dict_flush(const Tile &T, const BlockDict 
             if (si != 0.0) atomic_add_f64(&acc[tid], si);
         }
     }
+#ifndef EMSAR_EXP_NO_FAR_FLUSH
     if ((int)threadIdx.x >= emsar::kDictBlocks) {      // the far entries this thread fetched: the accumulator IS the transcript's sum (its mass, in deterministic mode)
         const int nb = ((int)T.near_n + kBlk - 1) / kBlk;
 #pragma unroll
         for (int i = 0; i < kBlk; i++) {
             if (D.tid[i] < 0) continue;
-            const int e = NE * nb + ((int)threadIdx.x - emsar::kDictBlocks) + i * (kTiledThreads - emsar::kDictBlocks);
+            const int f = ((int)threadIdx.x - emsar::kDictBlocks) + i * (kTiledThreads - emsar::kDictBlocks), e = NE * nb + f;
             const double v = acc_w[e];
             if (fx != 0.0) { const long long iv = __double_as_longlong(v); if (iv != 0) atomic_add_i64(&acc[D.tid[i]], iv); }
             else if (v != 0.0) atomic_add_f64(&acc[D.tid[i]], v);
         }
     }
+#endif
 }
 
 // M-step of up to 8 backward segments of one lane ({column, 11 row ids} each).  A lane's segments are consecutive
@@ -284,12 +286,28 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     return t;
 }
 
+// chip-wide 100 MHz clock and the place a wave runs at (timeline of the stamped instance)
+__device__ __forceinline__ unsigned long long stamp_real() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ unsigned stamp_place() {        // XCC_ID << 16 | HW_ID[15:0] (wave, simd, pipe, cu, sh, se)
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+    return (xcc & 0xFu) << 16 | (hw & 0xFFFFu);
+}
+
 // sum_i log S_i over a lane's kRPL unweighted rows (S_i <= 0: row outside F or padding, no term) with two logs instead of
 // twelve: log of the product of the twelve row sums of a lane (of six, of one, as the range allows).  A product that leaves [1e-280, 1e280] (components decayed towards the
 // boundary) falls back to the per-row logs.  The f64 log is ~40 VALU instructions: 19 % of a likelihood pass on config 3.
 // (the fallback is a rolled loop over LDS: fifteen inlined copies of the f64 log made the likelihood variant of the unit kernel
 // 65 KB of code, more than the instruction cache two CUs share; an out-of-line function cost scratch for its call frame)
 // w_s: the wave's own row-weight region of LDS, free at this point of the E-step (written right afterwards): scratch of the fallback
+// the likelihood terms a lane collects in the unit and multi kernels: sum of r log S (weighted rows), or the product of the row sums
+// as mantissa and exponent (unweighted rows; tile_e_step)
+struct LlAcc { double v = 0.0, p = 1.0; int e = 0; };
+__device__ __forceinline__ double ll_value(const LlAcc &a) { return a.v + (log(a.p) + (double)a.e * 0.6931471805599453094); }
 template <int N>
 __device__ __forceinline__ double sum_log_rows(const double (&S)[N], double *w_s, int lane) {
     static_assert(N == 12, "rows per lane");
@@ -475,7 +493,7 @@ __device__ __forceinline__ TileWave tile_wave(const Tile &T, int wave, int lane,
 }
 template <bool WEIGHTED, int MODE>
 __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], size_t slot0, const int32_t *wgt, const double *th_w, double *w_s,
-                                            int lane, double &ll) {
+                                            int lane, LlAcc &ll) {
     const unsigned th_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(th_w));
     double S[kRPL], w[kRPL], r[kRPL];
 #pragma unroll
@@ -489,13 +507,26 @@ __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], siz
 #pragma unroll
         for (int i = 0; i < kRPL; i++) r[i] = (double)__builtin_nontemporal_load(&wgt[slot0 + 64 * i]);
     }
+    // Unweighted likelihood: sum log S = log(product of the mantissas) + ln 2 * (sum of the exponents).  Four VALU instructions per row
+    // and NO log here -- one per lane at the end of the kernel (ll_value): the f64 log (about 40 instructions, a dozen temporaries)
+    // inside the E-step, with the weights and both index batches in registers, spilt 5-13 registers in the likelihood variants;
+    // no product can leave the double range either, whatever theta (the old two-product form needed a per-row fallback).
+    if (MODE == MODE_EM_LL && !WEIGHTED) {
+#pragma unroll
+        for (int i = 0; i < kRPL; i++) {
+            const bool pos = S[i] > 0.0;
+            ll.p *= pos ? __builtin_amdgcn_frexp_mant(S[i]) : 1.0;         // [0.5, 1): twelve of them stay above 2^-12
+            ll.e += pos ? __builtin_amdgcn_frexp_exp(S[i]) : 0;
+        }
+        ll.e += __builtin_amdgcn_frexp_exp(ll.p);
+        ll.p = __builtin_amdgcn_frexp_mant(ll.p);
+    }
 #pragma unroll
     for (int i = 0; i < kRPL; i++) {
         bool live = (S[i] > 0.0) && (r[i] > 0.0);
         w[i] = live ? r[i] / S[i] : 0.0;
-        if (MODE == MODE_EM_LL && WEIGHTED && live) ll += r[i] * log(S[i]);
+        if (MODE == MODE_EM_LL && WEIGHTED && live) ll.v += r[i] * log(S[i]);
     }
-    if (MODE == MODE_EM_LL && !WEIGHTED) ll += sum_log_rows(S, w_s, lane);
 #pragma unroll
     for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = w[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -528,7 +559,7 @@ struct TileEnv {            // per-launch constants of the multi-tile kernel
 // keeps loop-carried register arrays of this size in scratch.
 template <bool WEIGHTED, int MODE, int I, int N>
 __device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const Tile &T, const TileWave &W, int4 (&A)[8], int4 (&B)[8],
-                                            BlockDict &D, double &ll) {
+                                            BlockDict &D, LlAcc &ll) {
     block_dict_store(T, D, V.th_w, V.acc_w);
     const BlockDict Dcur = D;                     // tids of THIS tile's block, for its flush; D is refilled for the next tile below
     const int in = it + V.stride;
@@ -576,10 +607,10 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Til
         if (W.m > 0) load8_clamped(B, W.b, W.m < 8 ? W.m : 8);
     }
     if (V.lane < 8) V.w_s[emsar::kTileSliceRows + V.lane] = 0.0;
-    double ll = 0.0;
+    LlAcc ll;
     tiled_stage<WEIGHTED, MODE, 0, N>(V, (int)blockIdx.x, T, W, A, B, D, ll);
     if (MODE == MODE_EM_LL) {
-        double t = block_sum<kTiledThreads>(ll, red);
+        double t = block_sum<kTiledThreads>(ll_value(ll), red);
         if (threadIdx.x == 0 && t != 0.0) ll_add(ll_out, t, fx.ll);
     }
 }
@@ -602,13 +633,13 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *th_w = lds, *acc_w = lds + kTiledDictPad, *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, te = 0, tm = 0;      // STAMP: shader-clock stamps of the phases (diagnostic instance only)
-    if (STAMP) ts0 = stamp_now();
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, te = 0, tm = 0, tr0 = 0;      // STAMP: shader-clock stamps of the phases (diagnostic instance only)
+    if (STAMP) { ts0 = stamp_now(); tr0 = stamp_real(); }
     const Tile *tiles = utiles + (size_t)blockIdx.x * (size_t)stride;          // the unit's tiles and far list: addresses known from the start
     BlockDict D;
     block_dict_far_issue(ufar + (size_t)blockIdx.x * (size_t)far_stride, far_stride, D);
     Tile T = tiles[0];
-    const int dict_near_n = (int)T.near_n;                                       // the dictionary is the unit's, not the tile's
+    const int dict_near_n = (int)T.near_n, dict_lo = T.lo;                       // the dictionary is the unit's, not the tile's
     // The slices of a unit are in descending order of work (layout_tiled.hpp); wave w takes slice w of the unit's first and third
     // tile and slice 3 - w of the second and fourth: the wave with the longest slice of one tile has the shortest of the next.
     int slice = wave;
@@ -624,7 +655,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     if (STAMP) ts1 = stamp_now();
     __syncthreads();
     if (STAMP) ts2 = stamp_now();
-    double ll = 0.0;
+    LlAcc ll;
     int n_done = 0;
     for (int t = 0;; t++) {
         unsigned long long ta = 0, tb = 0;
@@ -646,16 +677,29 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     }
     unsigned long long ts3 = 0, ts4 = 0;
     if (STAMP) ts3 = stamp_now();
+    // The transcripts of the dictionary are fetched / derived again for the flush instead of being kept: five registers held across
+    // the E- and M-steps were five registers spilt (128 VGPRs at four workgroups per CU); the far list is an L2 hit by now and its
+    // latency is covered by the barrier.
+    block_dict_far_issue(ufar + (size_t)blockIdx.x * (size_t)far_stride, far_stride, D);
     __syncthreads();
     if (STAMP) ts4 = stamp_now();
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int sl = (int)threadIdx.x + j * kTiledThreads;
+        D.stid[j] = sl < dict_near_n ? dict_lo + sl : -1;
+    }
     T.near_n = (uint16_t)dict_near_n;            // (T is the last tile read by now: an absent one when the unit has fewer tiles than the stride)
     block_dict_flush(T, D, th_w, acc_w, acc, fx.mass);
     if (STAMP && lane == 0) {      // [unit][wave]: descriptor + dictionary + first loads, barrier, E-steps, M-steps, barrier, flush, tiles
         unsigned long long *o = stamps + ((size_t)blockIdx.x * (kTiledThreads / 64) + wave) * 8;
         o[0] = ts1 - ts0; o[1] = ts2 - ts1; o[2] = te; o[3] = tm; o[4] = ts4 - ts3; o[5] = stamp_now() - ts4; o[6] = n_done; o[7] = ts3 - ts2 - te - tm;
+        if (wave == 0) {           // the workgroup's timeline record, behind the per-wave records: start, end (100 MHz), place
+            unsigned long long *g = stamps + (size_t)gridDim.x * (kTiledThreads / 64) * 8 + (size_t)blockIdx.x * 4;
+            g[0] = tr0; g[1] = stamp_real(); g[2] = stamp_place(); g[3] = (unsigned long long)n_done;
+        }
     }
     if (MODE == MODE_EM_LL) {
-        double t = block_sum<kTiledThreads>(ll, red);
+        double t = block_sum<kTiledThreads>(ll_value(ll), red);
         if (threadIdx.x == 0 && t != 0.0) ll_add(ll_out, t, fx.ll);
     }
 }

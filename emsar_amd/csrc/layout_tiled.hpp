@@ -805,6 +805,13 @@ inline void build_unit_tables(const TiledLayout &L, UnitTables &U) {
         const Tile &T = L.tiles[a];
         for (uint32_t f = 0; f < T.far_n; f++) U.ufar[u * (size_t)U.far_stride + f] = L.far_tid[(size_t)T.far_off + f];
     }
+    if (getenv("EMSAR_HIP_DEBUG")) {
+        std::vector<uint32_t> cnt((size_t)L.n_tx, 0);
+        size_t slots = 0, with = 0; uint32_t mx = 0;
+        for (int32_t t : U.ufar) if (t >= 0) { cnt[(size_t)t]++; slots++; }
+        for (uint32_t c : cnt) { with += c > 0; mx = std::max(mx, c); }
+        fprintf(stderr, "unit tables: %zu units, stride %d, far stride %d, %zu far slots of %zu transcripts (most per transcript %u)\n", nu, stride, U.far_stride, slots, with, mx);
+    }
 }
 
 // Decode and compare with the input (host self-check, used by the CPU tests). 0 = identical.
