@@ -198,7 +198,9 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
             else if (!ctx->weighted && (ctx->tiled_multi >= 2 || (ctx->tiled_multi == 1 && ctx->n_tiles > kPairMinTiles))) {
                 // more than one tile per workgroup.  Unweighted rows only: with the row weights in registers as well the body does not
                 // fit 128 VGPRs (round 1, two tiles: 0.218 vs 0.179 ms; round 2, the unit kernel on merged rows, 72-92 B of scratch:
-                // 0.124 vs 0.103 ms with one tile per workgroup).
+                // 0.124 vs 0.103 ms with one tile per workgroup; with the weights kept as integers its EM variant fits without
+                // scratch and runs config 3's merged rows in 0.0959 ms against 0.0956 ms for one tile per workgroup: no gain,
+                // and the likelihood variant -- twelve logs -- still spills).
                 // Only when the tiles outnumber the chip's workgroup slots: below that a pass is one workgroup's latency, and
                 // a pair takes twice as long as a tile (40 k reads: 47 -> 26 us per pass with one tile per workgroup)
                 if (ctx->tiled_multi == 1 || ctx->tiled_multi == 5) {         // units: one dictionary for up to two tiles

@@ -495,9 +495,10 @@ template <bool WEIGHTED, int MODE>
 __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], size_t slot0, const int32_t *wgt, const double *th_w, double *w_s,
                                             int lane, LlAcc &ll) {
     const unsigned th_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(th_w));
-    double S[kRPL], w[kRPL], r[kRPL];
+    double S[kRPL];
+    int r[kRPL];                 // row weights (read counts) stay integers until they are used: 12 registers, not 24
 #pragma unroll
-    for (int i = 0; i < kRPL; i++) { S[i] = 0.0; r[i] = 1.0; }
+    for (int i = 0; i < kRPL; i++) { S[i] = 0.0; r[i] = 1; }
     for (int j0 = 0; j0 < W.k; j0 += 8) {
         const int n0 = W.k - j0 < 8 ? W.k - j0 : 8;
         if (j0) load8_clamped(A, W.e + (size_t)j0 * 64, n0);
@@ -505,7 +506,7 @@ __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], siz
     }
     if (WEIGHTED) {
 #pragma unroll
-        for (int i = 0; i < kRPL; i++) r[i] = (double)__builtin_nontemporal_load(&wgt[slot0 + 64 * i]);
+        for (int i = 0; i < kRPL; i++) r[i] = __builtin_nontemporal_load(&wgt[slot0 + 64 * i]);
     }
     // Unweighted likelihood: sum log S = log(product of the mantissas) + ln 2 * (sum of the exponents).  Four VALU instructions per row
     // and NO log here -- one per lane at the end of the kernel (ll_value): the f64 log (about 40 instructions, a dozen temporaries)
@@ -523,12 +524,11 @@ __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], siz
     }
 #pragma unroll
     for (int i = 0; i < kRPL; i++) {
-        bool live = (S[i] > 0.0) && (r[i] > 0.0);
-        w[i] = live ? r[i] / S[i] : 0.0;
-        if (MODE == MODE_EM_LL && WEIGHTED && live) ll.v += r[i] * log(S[i]);
+        const bool live = (S[i] > 0.0) && (r[i] > 0);
+        const double ri = WEIGHTED ? (double)r[i] : 1.0;
+        w_s[64 * i + lane] = live ? ri / S[i] : 0.0;
+        if (MODE == MODE_EM_LL && WEIGHTED && live) ll.v += ri * log(S[i]);
     }
-#pragma unroll
-    for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = w[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -5,7 +5,7 @@ cfg = sys.argv[1]
 code = ("import sys; sys.path.insert(0, %r)\n"
         "from emsar_amd import EmsarHip, synth\n"
         "s = synth.make_config(%r, 1.0)\n"
-        "d = EmsarHip(0); d.upload_structure(s['n_tx'], s['row_ptr'], s['col_idx'], 3); d.upload_sample(None, None, s['den']); d.run_passes(50)\n"
+        "d = EmsarHip(0); d.upload_structure(s['n_tx'], s['row_ptr'], s['col_idx'], int(__import__('os').environ.get('AB_LAYOUT', '3'))); d.upload_sample(None, None, s['den']); d.run_passes(50)\n"
         "print(min(d.run_passes(200) / 200 for _ in range(5)))\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cfg)
 for rep in range(2):
     for lib in libs:
