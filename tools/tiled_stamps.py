@@ -56,3 +56,16 @@ xcc = place >> 16
 for x in np.unique(xcc):
     m = xcc == x
     print("          XCD %d: %d workgroups, last end %.1f us, mean life %.2f us" % (x, m.sum(), en[m].max(), life[m].mean()))
+# slot turnover: on every CU, the time its four workgroup slots were empty between the first start and the last start there,
+# per workgroup that started after the first four (= what a finished workgroup's successor waited to begin)
+idle = []
+for c in range(cnt.size):
+    m = inv == c
+    s_c, e_c = np.sort(st[m]), en[m]
+    t_a, t_b = s_c[min(3, s_c.size - 1)], s_c[-1]          # window: all four slots taken ... last start
+    if t_b <= t_a or s_c.size <= 4:
+        continue
+    busy = (np.minimum(e_c, t_b) - np.maximum(st[m], t_a)).clip(min=0).sum()
+    idle.append((4 * (t_b - t_a) - busy) / (s_c.size - 4))
+idle = np.array(idle)
+print("          empty slot time per successor workgroup: mean %.2f us (p10 %.2f, p90 %.2f)" % (idle.mean(), *np.percentile(idle, [10, 90])))
