@@ -1123,7 +1123,7 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
         emsar::TiledLayout L;
         if (emsar::build_tiled(n_rows, n_tx, row_ptr, col_idx, L, merge_rows != 0) != 0) return EMSAR_HIP_ERR_ARG;
         int rc = emsar::check_tiled(L, row_ptr, col_idx);
-        { emsar::UnitTables U; emsar::build_unit_tables(L, U); }       // (debug statistics; the tables are checked by the GPU parity tests)
+        if (rc == 0) { emsar::UnitTables U; emsar::build_unit_tables(L, U); rc = emsar::check_unit_tables(L, U); }     // what k_pass_tiled_unit reads first
         if (info_out) {
             memset(info_out, 0, sizeof(*info_out));
             info_out->n_rows = n_rows; info_out->nnz = L.nnz; info_out->n_tx = n_tx;

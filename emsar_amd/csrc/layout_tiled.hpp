@@ -814,6 +814,29 @@ inline void build_unit_tables(const TiledLayout &L, UnitTables &U) {
     }
 }
 
+// the unit tables against the layout they were made from (host self-check): 0 = consistent
+inline int check_unit_tables(const TiledLayout &L, const UnitTables &U) {
+    const size_t nu = L.unit_first.empty() ? 0 : L.unit_first.size() - 1;
+    if (U.stride < 1 || U.stride > kUnitMaxTiles || U.far_stride < 8 || U.far_stride % 8 || U.far_stride > (kFarMax + 7) / 8 * 8) return -40;
+    if (U.utiles.size() != nu * (size_t)U.stride || U.ufar.size() != nu * (size_t)U.far_stride) return -41;
+    for (size_t u = 0; u < nu; u++) {
+        const uint32_t a = L.unit_first[u], b = L.unit_first[u + 1];
+        if (b - a > (uint32_t)U.stride) return -42;
+        for (int j = 0; j < U.stride; j++) {
+            const Tile &X = U.utiles[u * (size_t)U.stride + (size_t)j];
+            if (a + (uint32_t)j < b) { if (std::memcmp(&X, &L.tiles[a + (uint32_t)j], sizeof(Tile)) != 0) return -43; }
+            else if (X.n_slices != 0) return -44;               // the kernel stops at the first tile without slices
+        }
+        const Tile &T = L.tiles[a];
+        if ((int)T.far_n > U.far_stride) return -45;
+        for (int f = 0; f < U.far_stride; f++) {
+            const int32_t t = U.ufar[u * (size_t)U.far_stride + (size_t)f];
+            if (f < (int)T.far_n ? (t != L.far_tid[(size_t)T.far_off + (size_t)f] || t < 0 || t >= L.n_tx) : t != -1) return -46;
+        }
+    }
+    return 0;
+}
+
 // Decode and compare with the input (host self-check, used by the CPU tests). 0 = identical.
 inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int32_t *col_idx) {
     if (const int ext = check_tiled_extents(L)) return ext;          // the decode below indexes the arrays by the descriptors

@@ -36,6 +36,12 @@ int main(int argc, char **argv) {
             int rc = emsar::build_tiled(n_rows, n_tx, rp.data(), ci.data(), L, merge);
             int ck = rc ? -99 : emsar::check_tiled(L, rp.data(), ci.data());
             if (rc || ck) { printf("FAIL trial %d merge %d rc %d ck %d\n", trial, merge, rc, ck); return 1; }
+            {                                                                    // what the unit kernel reads first, derived from the layout
+                emsar::UnitTables U;
+                emsar::build_unit_tables(L, U);
+                const int cu = emsar::check_unit_tables(L, U);
+                if (cu) { printf("FAIL trial %d merge %d unit tables %d\n", trial, merge, cu); return 1; }
+            }
             if (!L.tiles.empty()) {                                              // a descriptor that points past its arrays must be caught on the host
                 size_t last = 0;
                 for (size_t i = 0; i < L.tiles.size(); i++) if (L.tiles[i].fwd_off > L.tiles[last].fwd_off) last = i;
