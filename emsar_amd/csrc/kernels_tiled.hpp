@@ -23,9 +23,6 @@ namespace {
 #ifndef EMSAR_UE_BATCH          // LDS gathers in flight per step of the E / M loops of the unit and multi kernels (tile_e_step,
 #define EMSAR_UE_BATCH 6        // tile_m_step); 6 / 12 in any combination measured 0.1159 - 0.1165 ms: no difference
 #endif
-#ifndef EMSAR_UNIT_MIRROR       // 1: the waves take the slices of every other tile of a unit in reverse order (k_pass_tiled_unit)
-#define EMSAR_UNIT_MIRROR 1
-#endif
 #ifndef EMSAR_UM_BATCH
 #define EMSAR_UM_BATCH 6
 #endif
@@ -466,14 +463,15 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
 // ------------------------------------------------------------------------------------------------
 struct TileWave {           // what one wave needs to know about its slice of a tile (all wave-uniform but e/b)
     const int4 *e, *b;
-    int k, m, nd;
+    int k, m, nd, slice;
     unsigned coo_base, coo_n;
     bool has_slice;
 };
 __device__ __forceinline__ TileWave tile_wave(const Tile &T, int wave, int lane, const uint32_t *fwd, const uint32_t *bwd) {
     TileWave W;
     W.nd = (int)T.near_n + (int)T.far_n;
-    W.has_slice = wave < (int)T.n_slices;
+    W.has_slice = wave >= 0 && wave < (int)T.n_slices;          // (wave = the slice index; -1: this wave has none in the tile)
+    W.slice = wave;
     W.e = nullptr; W.b = nullptr; W.k = 0; W.m = 0; W.coo_base = T.coo_off; W.coo_n = 0;
     if (W.has_slice) {
         unsigned foff = 0, boff = 0;
@@ -490,6 +488,14 @@ __device__ __forceinline__ TileWave tile_wave(const Tile &T, int wave, int lane,
         W.b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 4 + (size_t)boff * 256) + lane;
     }
     return W;
+}
+// the slice of tile T that wave `wave` of a unit's workgroup takes, -1 if none (Tile::wave_of)
+__device__ __forceinline__ int unit_slice(const Tile &T, int wave) {
+    int slice = -1;
+#pragma unroll
+    for (int s = 0; s < emsar::kTileSlices; s++)
+        if (s < (int)T.n_slices && (((unsigned)T.wave_of >> (2 * s)) & 3u) == (unsigned)wave) slice = s;
+    return slice;
 }
 template <bool WEIGHTED, int MODE>
 __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], size_t slot0, const int32_t *wgt, const double *th_w, double *w_s,
@@ -640,10 +646,8 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     block_dict_far_issue(ufar + (size_t)blockIdx.x * (size_t)far_stride, far_stride, D);
     Tile T = tiles[0];
     const int dict_near_n = (int)T.near_n, dict_lo = T.lo;                       // the dictionary is the unit's, not the tile's
-    // The slices of a unit are in descending order of work (layout_tiled.hpp); wave w takes slice w of the unit's first and third
-    // tile and slice 3 - w of the second and fourth: the wave with the longest slice of one tile has the shortest of the next.
-    int slice = wave;
-    TileWave W = tile_wave(T, slice, lane, fwd, bwd);
+    // which slice of a tile a wave takes is the layout's choice (Tile::wave_of: slices dealt to the waves by work)
+    TileWave W = tile_wave(T, unit_slice(T, wave), lane, fwd, bwd);
     int4 A[8], B[8];
     block_dict_issue<MODE, true>(T, W.nd, nullptr, theta, D);
     if (W.has_slice) {
@@ -660,11 +664,10 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     for (int t = 0;; t++) {
         unsigned long long ta = 0, tb = 0;
         if (STAMP) ta = stamp_now();              // the tiles of the unit, one after the other, on the same table
-        if (W.has_slice) tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)slice * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
+        if (W.has_slice) tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)W.slice * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
         const Tile Tn = tiles[t + 1 < stride ? t + 1 : t];
         const bool more = t + 1 < stride && Tn.n_slices > 0;
-        slice = EMSAR_UNIT_MIRROR ? emsar::kTileSlices - 1 - slice : slice;
-        TileWave Wn = tile_wave(Tn, slice, lane, fwd, bwd);
+        TileWave Wn = tile_wave(Tn, unit_slice(Tn, wave), lane, fwd, bwd);
         if (!more) Wn.has_slice = false;
         if (STAMP) tb = stamp_now();
         if (Wn.has_slice) load8_clamped(A, Wn.e, Wn.k < 8 ? Wn.k : 8);        // the next tile's forward columns during this one's M-step

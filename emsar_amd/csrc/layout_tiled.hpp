@@ -138,7 +138,8 @@ struct Tile {                // 64 bytes
     int32_t lo;              // dictionary slot d < near_n  <->  tid lo + d
     uint16_t near_n, far_n;  // slot near_n + i <-> far_tid[far_off + i]; slots near_n + far_n .. 359 are empty (theta 0)
     uint16_t n_slices;       // <= 4
-    uint16_t follows;        // 1: this tile uses the dictionary of the tile before it (second half of a unit of up to 8 slices)
+    uint8_t follows;         // 1: this tile uses the dictionary of the tile before it (a unit of up to 8 slices)
+    uint8_t wave_of;         // in a unit: slice s belongs to wave (wave_of >> 2s) & 3 of the workgroup (k_pass_tiled_unit; distinct waves)
     uint16_t k[4];           // padded row length of each slice's forward index
     uint16_t m[4];           // backward segments (int4) per lane of each slice
     uint16_t coo_n[4];       // COO pairs of each slice
@@ -244,6 +245,9 @@ inline int check_tiled_extents(const TiledLayout &L) {
     for (size_t i = 0; i < L.tiles.size(); i++) {            // a tile that follows shares the dictionary of the tile before it
         const Tile &T = L.tiles[i];
         if (T.follows > 1 || (T.follows && i == 0)) return -30;
+        for (int a = 0; a < T.n_slices; a++)
+            for (int b = a + 1; b < T.n_slices; b++)
+                if (((T.wave_of >> (2 * a)) & 3) == ((T.wave_of >> (2 * b)) & 3)) return -32;      // two slices of a tile on one wave
         if (T.follows) {
             const Tile &P = L.tiles[i - 1];
             if (P.lo != T.lo || P.near_n != T.near_n || P.far_n != T.far_n || P.far_off != T.far_off) return -30;
@@ -423,6 +427,10 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     int32_t block = 128;       // the rows of one block of the sort fit one dictionary (360 transcripts) with room for their far hits;
                                // config 3, rows sorted by entry count inside a block: 96 / 128 / 160 / 192 tids -> 0.1178 / 0.1169 / 0.1187 / 0.124 ms per pass
     if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 900) block = v; }
+    int short_ecnt = 0; int32_t short_block = 512;      // rows of <= short_ecnt entries: sort block short_block (0 = no such class)
+    if (const char *e = getenv("EMSAR_HIP_SHORT_ECNT")) { int v = atoi(e); if (v >= 0 && v <= 32) short_ecnt = v; }
+    if (const char *e = getenv("EMSAR_HIP_SHORT_BLOCK")) { int v = atoi(e); if (v >= block && v <= (1 << 20)) short_block = v; }
+    if (short_block < block) short_block = block;
     int64_t tile_rows = kTileRows;
     int unit_tiles = 2;                 // tiles that may share one dictionary (a unit: one workgroup, one dictionary load, one flush)
     if (const char *e = getenv("EMSAR_HIP_UNIT_TILES")) { int v = atoi(e); if (v >= 1 && v <= kUnitMaxTiles) unit_tiles = v; }
@@ -432,6 +440,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     if (const char *e = getenv("EMSAR_HIP_TILE_DENSE")) { int v = atoi(e); if (v >= 1 && v <= 64) dense_min = v; }
     bool unit_sort = true;
     if (const char *e = getenv("EMSAR_HIP_UNIT_SORT")) unit_sort = atoi(e) != 0;
+    bool unit_lpt = true;               // slices dealt to the waves by work (0: in order, alternate tiles mirrored)
+    if (const char *e = getenv("EMSAR_HIP_UNIT_LPT")) unit_lpt = atoi(e) != 0;
     bool cut_at_slices = true;
     if (const char *e = getenv("EMSAR_HIP_TILE_CUT")) cut_at_slices = atoi(e) != 0;
     const auto tp1 = t_now();
@@ -465,8 +475,12 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         counting_sort(act, pa, (size_t)n_tx, [&](uint32_t r) { return (size_t)mintid[r]; });
         std::vector<uint32_t>().swap(act);
         const int64_t n_blocks = ((int64_t)n_tx + block - 1) / block;
-        counting_sort(pa, perm, (size_t)(n_blocks * kLenClasses), [&](uint32_t r) {
-            return (size_t)(mintid[r] / block) * kLenClasses + (size_t)len_class((int64_t)ecnt[r]);
+        // Rows of few entries touch few transcripts: they are sorted in WIDER blocks (their (block, count) buckets then hold several
+        // slices of equal rows -- no padding -- and a unit of them still spans a narrow range of anchors); they come after the others.
+        counting_sort(pa, perm, (size_t)(2 * n_blocks * kLenClasses), [&](uint32_t r) {
+            const int e = (int)ecnt[r];
+            if (e <= short_ecnt) return (size_t)(n_blocks + mintid[r] / short_block) * kLenClasses + (size_t)len_class((int64_t)e);
+            return (size_t)(mintid[r] / block) * kLenClasses + (size_t)len_class((int64_t)e);
         });
     }
     std::vector<uint32_t>().swap(pa);
@@ -594,12 +608,44 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 rent_ptr.push_back((uint32_t)rent.size());
                 out.tiled_entries += (int64_t)rents.size();
             }
-            // the rows of the unit go to its tiles in order, up to tile_rows each; the second tile `follows` the first
-            for (int64_t pa0 = i0; pa0 < i1; pa0 += tile_rows) {
-            const int64_t pa1 = std::min(i1, pa0 + tile_rows);
+            // The rows of the unit (longest first) are cut into slices of 768; the slices are dealt to the four waves of the workgroup,
+            // heaviest first, each to the wave with the least work so far (work = forward columns + entries: the first slice of a unit
+            // holds its long-row tail -- 18 columns on config 3 where the others have 2-7 -- and used to share a wave with the last one).
+            // Tile t of the unit holds the t-th slice of every wave that has one; Tile::follows says which wave takes which slice.
+            const int64_t n_chunks_u = (i1 - i0 + kTileSliceRows - 1) / kTileSliceRows;
+            std::vector<int> wave_slices[kTileSlices];
+            if (unit_lpt) {
+                std::vector<std::pair<int64_t, int>> cost((size_t)n_chunks_u);
+                for (int64_t c = 0; c < n_chunks_u; c++) {
+                    const int64_t a0 = i0 + c * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
+                    int64_t k = 0;
+                    for (int64_t i = a0; i < bnd; i++) k = std::max<int64_t>(k, (int64_t)(rent_ptr[(size_t)(i - i0) + 1] - rent_ptr[(size_t)(i - i0)]));
+                    cost[(size_t)c] = {k * kTileSliceRows + (int64_t)(rent_ptr[(size_t)(bnd - i0)] - rent_ptr[(size_t)(a0 - i0)]), (int)c};
+                }
+                std::stable_sort(cost.begin(), cost.end(), [](const std::pair<int64_t, int> &a, const std::pair<int64_t, int> &b) { return a.first > b.first; });
+                int64_t load[kTileSlices] = {0, 0, 0, 0};
+                for (const auto &cc : cost) {
+                    int w = -1;
+                    for (int q = 0; q < kTileSlices; q++)
+                        if ((int)wave_slices[q].size() < kUnitMaxTiles && (w < 0 || load[q] < load[w])) w = q;
+                    wave_slices[w].push_back(cc.second); load[w] += cc.first;
+                }
+            } else {                                      // in order, alternate tiles mirrored (the scheme before)
+                for (int64_t c = 0; c < n_chunks_u; c++) {
+                    const int64_t per = tile_rows / kTileSliceRows, t = c / per, s = c % per;
+                    wave_slices[(t & 1) ? (int)(kTileSlices - 1 - s) : (int)s].push_back((int)c);
+                }
+            }
+            size_t n_tiles_u = 0;
+            for (int q = 0; q < kTileSlices; q++) n_tiles_u = std::max(n_tiles_u, wave_slices[q].size());
+            for (size_t tu = 0; tu < n_tiles_u; tu++) {
+            int chunk_of[kTileSlices]; unsigned wave_map = 0; int ns = 0;
+            for (int q = 0; q < kTileSlices; q++)
+                if (wave_slices[q].size() > tu) { chunk_of[ns] = wave_slices[q][tu]; wave_map |= (unsigned)q << (2 * ns); ns++; }
             T = Tdict;
-            T.follows = pa0 > i0 ? 1 : 0;
-            T.n_slices = (uint16_t)((pa1 - pa0 + kTileSliceRows - 1) / kTileSliceRows);
+            T.follows = tu > 0 ? 1 : 0;
+            T.wave_of = (uint8_t)wave_map;
+            T.n_slices = (uint16_t)ns;
             T.row_base = (uint32_t)out.slot_row.size();
             out.slot_row.resize(out.slot_row.size() + (size_t)T.n_slices * kTileSliceRows, -1);
             T.fwd_off = (uint64_t)out.fwd.size() * 4;
@@ -611,7 +657,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             //    lanes of one E-step gather read 64 CONSECUTIVE sorted rows, i.e. mostly one family -- the same few
             //    table entries (LDS broadcast) or neighbouring ones (distinct banks) instead of a random spread
             for (int s = 0; s < T.n_slices; s++) {
-                int64_t a0 = pa0 + (int64_t)s * kTileSliceRows, bnd = std::min(pa1, a0 + kTileSliceRows);
+                int64_t a0 = i0 + (int64_t)chunk_of[s] * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
                 int64_t k = 0;
                 for (int64_t i = a0; i < bnd; i++) k = std::max<int64_t>(k, (int64_t)(rent_ptr[(size_t)(i - i0) + 1] - rent_ptr[(size_t)(i - i0)]));
                 T.k[s] = (uint16_t)k;
@@ -634,7 +680,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             }
             // 4. backward index of each slice: its (entry value, row) pairs sorted by entry value
             for (int s = 0; s < T.n_slices; s++) {
-                int64_t a0 = pa0 + (int64_t)s * kTileSliceRows, bnd = std::min(pa1, a0 + kTileSliceRows);
+                int64_t a0 = i0 + (int64_t)chunk_of[s] * kTileSliceRows, bnd = std::min(i1, a0 + kTileSliceRows);
                 pairs.clear();
                 for (int64_t i = a0; i < bnd; i++) {
                     uint32_t in_slice = (uint32_t)(i - a0);
