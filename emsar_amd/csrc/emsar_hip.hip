@@ -64,7 +64,7 @@ struct emsar_hip_ctx {
     // TILED layout
     emsar::TiledLayout TL;       // host copy keeps slot_row / single_* / left_row (index arrays freed after upload)
     Tile *d_tiles = nullptr;
-    Tile *d_utiles = nullptr; int32_t *d_ufar = nullptr; int unit_stride = 1, far_stride = 8;   // emsar::UnitTables
+    Tile *d_utiles = nullptr; int unit_stride = 1;   // emsar::UnitTables
     uint32_t *d_units = nullptr; int64_t n_units = 0;     // units of one or two tiles that share a dictionary (k_pass_tiled_unit)
     uint32_t *d_fwd = nullptr, *d_bwd = nullptr;
     uint32_t *d_coo = nullptr;
@@ -165,7 +165,7 @@ void free_structure(emsar_hip_ctx *ctx) {
     ctx->d_row_ptr = nullptr; ctx->d_col = nullptr;
     dfree(ctx->d_wgt); dfree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
     dfree(ctx->d_units); ctx->d_units = nullptr; ctx->n_units = 0;
-    dfree(ctx->d_utiles); dfree(ctx->d_ufar); ctx->d_utiles = nullptr; ctx->d_ufar = nullptr;
+    dfree(ctx->d_utiles); ctx->d_utiles = nullptr;
     dfree(ctx->d_tiles); dfree(ctx->d_fwd); dfree(ctx->d_bwd); dfree(ctx->d_coo); dfree(ctx->d_far);
     dfree(ctx->d_left_ptr); dfree(ctx->d_left_col); dfree(ctx->d_left_wgt); dfree(ctx->d_left_val); dfree(ctx->d_u);
     ctx->d_tiles = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_coo = nullptr; ctx->d_far = nullptr;
@@ -205,7 +205,7 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
                 // a pair takes twice as long as a tile (40 k reads: 47 -> 26 us per pass with one tile per workgroup)
                 if (ctx->tiled_multi == 1 || ctx->tiled_multi == 5) {         // units: one dictionary for up to two tiles
 #define LAUNCH_U(WT, MD) hipLaunchKernelGGL((k_pass_tiled_unit<WT, MD>), dim3((unsigned)ctx->n_units), block, lds, ctx->stream, ctx->d_utiles, ctx->unit_stride, \
-                                           ctx->d_ufar, ctx->far_stride, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_wgt, theta, acc, ll_out, fx_of(ctx, mode))
+                                           ctx->d_far, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_wgt, theta, acc, ll_out, fx_of(ctx, mode))
                     if (mode == MODE_EM_LL) LAUNCH_U(false, MODE_EM_LL); else LAUNCH_U(false, MODE_EM);
 #undef LAUNCH_U
                 }
@@ -598,9 +598,8 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
             {
                 emsar::UnitTables U;
                 emsar::build_unit_tables(L, U);
-                ctx->unit_stride = U.stride; ctx->far_stride = U.far_stride;
+                ctx->unit_stride = U.stride;
                 HIPCHK(up((void **)&ctx->d_utiles, U.utiles.data(), U.utiles.size() * sizeof(Tile)));
-                HIPCHK(up((void **)&ctx->d_ufar, U.ufar.data(), U.ufar.size() * 4));
             }
             HIPCHK(up((void **)&ctx->d_fwd, L.fwd.data(), L.fwd.size() * 4));
             HIPCHK(up((void **)&ctx->d_bwd, L.bwd.data(), L.bwd.size() * 4));
@@ -1099,7 +1098,7 @@ int emsar_hip_debug_unit_stamps(emsar_hip_ctx *ctx, double *out, unsigned long l
     const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
     HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_unit<false, MODE_EM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_pass_tiled_unit<false, MODE_EM, true>), dim3((unsigned)ctx->n_units), dim3(kTiledThreads), lds, ctx->stream, ctx->d_utiles, ctx->unit_stride,
-                       ctx->d_ufar, ctx->far_stride, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_wgt, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].s[0].v, Fx{0.0, 0.0}, d);
+                       ctx->d_far, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_wgt, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].s[0].v, Fx{0.0, 0.0}, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
     std::vector<unsigned long long> h(nw * 8 + (size_t)ctx->n_units * 4);

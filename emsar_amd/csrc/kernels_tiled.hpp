@@ -130,13 +130,13 @@ struct BlockDict { double th[kBlk]; int tid[kBlk]; int stid[2]; };     // stid: 
 constexpr int kSlotsPerThread = (emsar::kTileDict + kTiledThreads - 1) / kTiledThreads;
 static_assert(kSlotsPerThread == 2, "BlockDict::stid");
 static_assert(emsar::kFarMax == kBlk * (kTiledThreads - emsar::kDictBlocks), "three far entries per thread that owns no near block");
-// the far list of a unit from its fixed-stride copy (layout_tiled.hpp: UnitTables): needs no descriptor
-__device__ __forceinline__ void block_dict_far_issue(const int32_t *ufar, int far_stride, BlockDict &D) {
+// the far list of a unit (n transcripts at far), three per thread that owns no near block
+__device__ __forceinline__ void block_dict_far_issue(const int32_t *far, int n, BlockDict &D) {
 #pragma unroll
     for (int i = 0; i < kBlk; i++) {
         D.tid[i] = -1;
         const int f = ((int)threadIdx.x - emsar::kDictBlocks) + i * (kTiledThreads - emsar::kDictBlocks);
-        if ((int)threadIdx.x >= emsar::kDictBlocks && f < far_stride) D.tid[i] = __builtin_nontemporal_load(&ufar[f]);
+        if ((int)threadIdx.x >= emsar::kDictBlocks && f < n) D.tid[i] = __builtin_nontemporal_load(&far[f]);
     }
 }
 template <int MODE, bool FAR_ISSUED = false>
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Til
 // Tile 2's forward columns are requested while tile 1's M-step runs, its backward segments afterwards (as in k_pass_tiled_multi).
 // ------------------------------------------------------------------------------------------------
 template <bool WEIGHTED, int MODE, bool STAMP = false>
-__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile *__restrict__ utiles, int stride, const int32_t *__restrict__ ufar, int far_stride,
+__global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile *__restrict__ utiles, int stride, const int32_t *__restrict__ far_tid,
                                                                    const uint32_t *__restrict__ fwd, const uint32_t *__restrict__ bwd,
                                                                    const uint32_t *__restrict__ coo,
                                                                    const int32_t *__restrict__ wgt, const double *__restrict__ theta,
@@ -641,11 +641,14 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     double *th_w = lds, *acc_w = lds + kTiledDictPad, *w_s = lds + 2 * kTiledDictPad + wave * kTiledWr;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, te = 0, tm = 0, tr0 = 0;      // STAMP: shader-clock stamps of the phases (diagnostic instance only)
     if (STAMP) { ts0 = stamp_now(); tr0 = stamp_real(); }
-    const Tile *tiles = utiles + (size_t)blockIdx.x * (size_t)stride;          // the unit's tiles and far list: addresses known from the start
+    const Tile *tiles = utiles + (size_t)blockIdx.x * (size_t)stride;          // the unit's tiles: address known from the start
     BlockDict D;
-    block_dict_far_issue(ufar + (size_t)blockIdx.x * (size_t)far_stride, far_stride, D);
     Tile T = tiles[0];
-    const int dict_near_n = (int)T.near_n, dict_lo = T.lo;                       // the dictionary is the unit's, not the tile's
+    // (a copy of the far list at a fixed stride per unit, requested together with the descriptor, was measured: 1 % SLOWER than
+    // this dependent load -- the round trip it saves is not what the waves wait for, the unused tail of the list it reads is traffic)
+    block_dict_far_issue(far_tid + T.far_off, (int)T.far_n, D);
+    const int dict_near_n = (int)T.near_n, dict_lo = T.lo, dict_far_n = (int)T.far_n;
+    const uint32_t dict_far_off = T.far_off;                       // the dictionary is the unit's, not the tile's
     // which slice of a tile a wave takes is the layout's choice (Tile::wave_of: slices dealt to the waves by work)
     TileWave W = tile_wave(T, unit_slice(T, wave), lane, fwd, bwd);
     int4 A[8], B[8];
@@ -683,7 +686,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     // The transcripts of the dictionary are fetched / derived again for the flush instead of being kept: five registers held across
     // the E- and M-steps were five registers spilt (128 VGPRs at four workgroups per CU); the far list is an L2 hit by now and its
     // latency is covered by the barrier.
-    block_dict_far_issue(ufar + (size_t)blockIdx.x * (size_t)far_stride, far_stride, D);
+    block_dict_far_issue(far_tid + dict_far_off, dict_far_n, D);
     __syncthreads();
     if (STAMP) ts4 = stamp_now();
 #pragma unroll

@@ -828,43 +828,38 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     return ext == 0 ? 0 : ext;
 }
 
-// What k_pass_tiled_unit reads first, at addresses that depend on the workgroup index alone (nothing to chase: the descriptor and
-// the far list are requested together, the theta gather is the second memory round trip of a workgroup, not the fourth):
+// What k_pass_tiled_unit reads first, at an address that depends on the workgroup index alone (no unit -> tile index to chase):
 //   utiles[u * stride + j]   the j-th tile of unit u, j < stride = the most tiles any unit has; absent tiles have n_slices = 0
-//   ufar[u * far_stride + f] the unit's f-th far transcript, -1 beyond its far_n; far_stride = the longest far list, rounded up to 8
-struct UnitTables { std::vector<Tile> utiles; std::vector<int32_t> ufar; int stride = 1, far_stride = 8; };
+struct UnitTables { std::vector<Tile> utiles; int stride = 1; };
 inline void build_unit_tables(const TiledLayout &L, UnitTables &U) {
     const size_t nu = L.unit_first.empty() ? 0 : L.unit_first.size() - 1;
-    int stride = 1, far_max = 0;
-    for (size_t u = 0; u < nu; u++) {
-        stride = std::max(stride, (int)(L.unit_first[u + 1] - L.unit_first[u]));
-        far_max = std::max(far_max, (int)L.tiles[L.unit_first[u]].far_n);
-    }
-    U.stride = stride; U.far_stride = std::max(8, (far_max + 7) / 8 * 8);
+    int stride = 1;
+    for (size_t u = 0; u < nu; u++) stride = std::max(stride, (int)(L.unit_first[u + 1] - L.unit_first[u]));
+    U.stride = stride;
     Tile none;
     std::memset(&none, 0, sizeof none);
     U.utiles.assign(nu * (size_t)stride, none);
-    U.ufar.assign(nu * (size_t)U.far_stride, -1);
     for (size_t u = 0; u < nu; u++) {
         const uint32_t a = L.unit_first[u], b = L.unit_first[u + 1];
         for (uint32_t t = a; t < b; t++) U.utiles[u * (size_t)stride + (t - a)] = L.tiles[t];
-        const Tile &T = L.tiles[a];
-        for (uint32_t f = 0; f < T.far_n; f++) U.ufar[u * (size_t)U.far_stride + f] = L.far_tid[(size_t)T.far_off + f];
     }
     if (getenv("EMSAR_HIP_DEBUG")) {
         std::vector<uint32_t> cnt((size_t)L.n_tx, 0);
         size_t slots = 0, with = 0; uint32_t mx = 0;
-        for (int32_t t : U.ufar) if (t >= 0) { cnt[(size_t)t]++; slots++; }
+        for (size_t u = 0; u < nu; u++) {
+            const Tile &T = L.tiles[L.unit_first[u]];
+            for (uint32_t f = 0; f < T.far_n; f++) { cnt[(size_t)L.far_tid[(size_t)T.far_off + f]]++; slots++; }
+        }
         for (uint32_t c : cnt) { with += c > 0; mx = std::max(mx, c); }
-        fprintf(stderr, "unit tables: %zu units, stride %d, far stride %d, %zu far slots of %zu transcripts (most per transcript %u)\n", nu, stride, U.far_stride, slots, with, mx);
+        fprintf(stderr, "unit tables: %zu units, stride %d, %zu far slots of %zu transcripts (most per transcript %u)\n", nu, stride, slots, with, mx);
     }
 }
 
 // the unit tables against the layout they were made from (host self-check): 0 = consistent
 inline int check_unit_tables(const TiledLayout &L, const UnitTables &U) {
     const size_t nu = L.unit_first.empty() ? 0 : L.unit_first.size() - 1;
-    if (U.stride < 1 || U.stride > kUnitMaxTiles || U.far_stride < 8 || U.far_stride % 8 || U.far_stride > (kFarMax + 7) / 8 * 8) return -40;
-    if (U.utiles.size() != nu * (size_t)U.stride || U.ufar.size() != nu * (size_t)U.far_stride) return -41;
+    if (U.stride < 1 || U.stride > kUnitMaxTiles) return -40;
+    if (U.utiles.size() != nu * (size_t)U.stride) return -41;
     for (size_t u = 0; u < nu; u++) {
         const uint32_t a = L.unit_first[u], b = L.unit_first[u + 1];
         if (b - a > (uint32_t)U.stride) return -42;
@@ -872,12 +867,6 @@ inline int check_unit_tables(const TiledLayout &L, const UnitTables &U) {
             const Tile &X = U.utiles[u * (size_t)U.stride + (size_t)j];
             if (a + (uint32_t)j < b) { if (std::memcmp(&X, &L.tiles[a + (uint32_t)j], sizeof(Tile)) != 0) return -43; }
             else if (X.n_slices != 0) return -44;               // the kernel stops at the first tile without slices
-        }
-        const Tile &T = L.tiles[a];
-        if ((int)T.far_n > U.far_stride) return -45;
-        for (int f = 0; f < U.far_stride; f++) {
-            const int32_t t = U.ufar[u * (size_t)U.far_stride + (size_t)f];
-            if (f < (int)T.far_n ? (t != L.far_tid[(size_t)T.far_off + (size_t)f] || t < 0 || t >= L.n_tx) : t != -1) return -46;
         }
     }
     return 0;
