@@ -28,18 +28,91 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def _cfg(args, rank, structure):
+    from emsar_amd import synth
+    cfg = dict(synth.CONFIGS[args.config])
+    cfg["seed"] = cfg["seed"] + 100 * rank
+    if args.xfam is not None:
+        cfg["xfam"] = args.xfam
+    if args.scale != 1.0:
+        cfg["n_reads"] = max(1000, int(cfg["n_reads"] * args.scale))
+        cfg["n_tx"] = max(500, int(cfg["n_tx"] * args.scale))
+    cfg["structure"] = structure
+    return cfg
+
+
+def _traffic(args, structure, layout_name):
+    """HBM bytes per launch of the pass kernel from the PMC counters.  They cannot be read inside this process, so the value is the
+    committed rocprofv3 measurement of exactly this kernel + workload (profiles/traffic.json, tools/prof_round.sh), else None."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None
+    key = "%s/%s/%s" % (args.config, structure, layout_name)
+    if args.scale != 1.0 or args.xfam is not None or key not in tr:
+        return None
+    return tr[key]
+
+
+def _kernel_name(info, weighted):
+    multi = int(os.environ.get("EMSAR_HIP_TILED_MULTI", "1"))
+    if info["layout"] == 1:
+        return "k_pass_csr"
+    units = (multi == 5) or (multi == 1 and info["n_chunks"] > 2048)
+    if units:
+        return "k_pass_tiled_unit"
+    if not weighted and multi in (2, 3, 4):
+        return "k_pass_tiled_multi<%d>" % multi
+    return "k_pass_tiled"
+
+
+def _roofline(args, structure, info, per_pass_s, weighted=False, tag=""):
+    """frac = HBM bytes the counters saw per launch / device time per pass / 8 TB/s -- a fraction of the peak the memory system really
+    delivered.  The SURVEY 8d formula (what a CSR walk would stream) is reported as csr_equivalent_GBps: the TILED layout stores and
+    moves a third of those bytes, so that figure may exceed the HBM peak -- it is not a roofline fraction."""
+    layout_name = {1: "csr", 3: "tiled", 259: "tiled+merged-rows"}[info["layout"]] + tag
+    tr = _traffic(args, structure, layout_name)
+    r = {"bound": "latency", "bound_evidence": "PMC: HBM below its copy ceiling, SQ_WAIT_ANY > 50 % of wave cycles, LDS pipe < 50 % busy (profiles/)",
+         "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+         "kernel": _kernel_name(info, weighted) + "+k_update", "device_ms_per_pass": per_pass_s * 1e3,
+         "algorithmic_bytes_per_pass": info["bytes_per_pass"], "stored_bytes_per_pass": info["stored_bytes_per_pass"],
+         "csr_equivalent_GBps": info["bytes_per_pass"] / per_pass_s / 1e9,
+         "stored_GBps": info["stored_bytes_per_pass"] / per_pass_s / 1e9}
+    if tr is not None:
+        r["traffic"] = tr["hbm_bytes_per_launch"]
+        r["traffic_source"] = "profiles/traffic.json (rocprofv3 PMC run of this kernel and workload: %s)" % tr.get("profile", "")
+        r["achieved"] = tr["hbm_bytes_per_launch"] / per_pass_s / 1e9
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+    else:
+        r["note"] = "no PMC measurement committed for this workload: frac is null (stored_GBps / peak = %.3f is a lower bound of it)" % (
+            r["stored_GBps"] / HBM_PEAK_GBS)
+    return r
+
+
+def _layout_stats(info):
+    d = {k: info[k] for k in ("n_chunks", "n_units", "n_slices", "padded_entries", "far_entries", "window", "tiled_entries", "tiled_ids", "renumbered")}
+    d["tids_per_entry"] = info["tiled_ids"] / info["tiled_entries"] if info["tiled_entries"] else None
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--structure", default="family", choices=["window", "family", "family_shuffled"],
+                    help="row law of the synthetic matrix (emsar_amd/synth.py): SURVEY 8d's family subsets (default), the same with "
+                         "shuffled transcript ids, or consecutive-tid windows (the generator of rounds 1-2)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads and transcripts (debug only)")
     ap.add_argument("--layout", default="auto", choices=["auto", "csr", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip workload_variants and the collapsed form (profiling runs)")
     ap.add_argument("--xfam", type=float, default=None, help="experiment: override the config's share of cross-family reads")
     ap.add_argument("--merge-rows", action="store_true",
                     help="store identical rows once (read -> segment collapse at upload); NOT the headline configuration")
+    ap.add_argument("--collapsed", action="store_true",
+                    help="time the COLLAPSED form as the main workload: rows = segments with read counts (device collapse first)")
     ap.add_argument("--solve", type=float, default=1e-6, metavar="TOL",
                     help="after the timed passes, run the full solver (SQUAREM) on the same matrix to this tolerance and report passes / time "
                          "(BASELINE metric: 'to convergence'; config 5 names 1e-6); 0 = skip")
@@ -68,22 +141,22 @@ def main():
     group = D.Group(backend, torch.device("cuda", local_rank) if backend == "nccl" else None)
 
     # ---- workload: one independent sample per rank ------------------------------------------------------
-    cfg = dict(synth.CONFIGS[args.config])
-    cfg["seed"] = cfg["seed"] + 100 * rank
-    if args.xfam is not None:
-        cfg["xfam"] = args.xfam
-    if args.scale != 1.0:
-        cfg["n_reads"] = max(1000, int(cfg["n_reads"] * args.scale))
-        cfg["n_tx"] = max(500, int(cfg["n_tx"] * args.scale))
     t0 = time.time()
-    s = synth.make_matrix(**cfg)
+    s = synth.make_matrix(**_cfg(args, rank, args.structure))
     t_gen = time.time() - t0
     nnz = int(len(s["col_idx"]))
     layout = {"auto": LAYOUT_AUTO, "csr": LAYOUT_CSR, "tiled": 3}[args.layout]
     dev = EmsarHip(local_rank)
     t0 = time.time()
-    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], layout, merge_rows=args.merge_rows)
-    dev.upload_sample(None, None, s["den"])
+    collapsed_main = None
+    if args.collapsed:
+        rp_c, ci_c, w_c, _, cst = dev.collapse_rows(s["n_tx"], s["row_ptr"], s["col_idx"], want_map=False)
+        collapsed_main = {"rows": int(len(w_c)), "nnz": int(len(ci_c)), "collapse_kernel_ms": cst.kernel_ms}
+        dev.upload_structure(s["n_tx"], rp_c, ci_c, layout)
+        dev.upload_sample(w_c, None, s["den"])
+    else:
+        dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], layout, merge_rows=args.merge_rows)
+        dev.upload_sample(None, None, s["den"])
     t_up = time.time() - t0
     info = dev.info()
 
@@ -124,53 +197,99 @@ def main():
     out = None
     if rank == 0:
         per_pass_s = kernel_ms / 1e3 / args.steps
-        tiled_kernel = "k_pass_tiled_unit" if info["n_chunks"] > 2048 else "k_pass_tiled"     # units of two tiles above 2048 tiles, one tile per workgroup below
-        bytes_pass = info["bytes_per_pass"]
-        achieved = bytes_pass / per_pass_s / 1e9
+        form = "collapsed (segments x read counts)" if args.collapsed else "read-level CSR"
         out = {
             "metric": "EM iterations/s", "value": world * args.steps / wall, "unit": "iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d reads x %d transcripts, nnz %d (mean %.2f aln/read), read-level CSR, one sample per GPU"
-                       % (args.config, s["n_reads"], s["n_tx"], nnz, nnz / s["n_reads"]),
+            "config": {"workload": "%s: %d reads x %d transcripts, nnz %d (mean %.2f aln/read), row law '%s' (emsar_amd/synth.py), %s, one sample per GPU"
+                       % (args.config, s["n_reads"], s["n_tx"], nnz, nnz / s["n_reads"], args.structure, form),
+                       "structure": args.structure,
                        "layout": {1: "csr", 3: "tiled", 259: "tiled+merged-rows"}[info["layout"]], "parallelism": "1 sample per GPU x %d" % world},
             "read_alignments_per_s": world * nnz * args.steps / wall,
-            # achieved / frac: ALGORITHMIC bytes (SURVEY.md 8d formula, what a CSR walk would stream) per second -- the TILED layout stores
-            # and moves a third of them (stored_bytes_per_pass, traffic), so `achieved` exceeds the HBM peak and frac exceeds 1: the
-            # kernel is NOT running above the roofline, it reads fewer bytes than the formula counts.  hbm_actual_GBps / frac_actual
-            # below are the measured-traffic figures (what the HBM really delivered)
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": {1: "k_pass_csr", 3: tiled_kernel, 259: "k_pass_tiled"}[info["layout"]] + "+k_update",
-                         "algorithmic_bytes_per_pass": bytes_pass, "stored_bytes_per_pass": info["stored_bytes_per_pass"],
-                         "device_ms_per_pass": per_pass_s * 1e3},
-            "layout_stats": {k: info[k] for k in ("n_chunks", "n_slices", "padded_entries", "far_entries", "window")},
+            "roofline": _roofline(args, args.structure, info, per_pass_s, weighted=args.collapsed, tag="+collapsed" if args.collapsed else ""),
+            "layout_stats": _layout_stats(info),
             "setup_s": {"generate": round(t_gen, 2), "upload_and_layout": round(t_up, 2)},
             "mass_conserved": ok,
         }
+        if collapsed_main:
+            out["config"]["collapsed"] = collapsed_main
         if solve is not None:
             out["solve_to_convergence"] = solve
-        # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the value is the
-        # committed rocprofv3 measurement of exactly this kernel + workload (profiles/traffic.json), else null
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            key = "%s/%s" % (args.config, out["config"]["layout"])
-            if args.scale == 1.0 and key in tr and args.xfam is None and not args.merge_rows:
-                out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 PMC run of this kernel and workload)"
-                out["roofline"]["hbm_actual_GBps"] = tr[key]["hbm_bytes_per_launch"] / per_pass_s / 1e9
-                out["roofline"]["frac_actual"] = out["roofline"]["hbm_actual_GBps"] / HBM_PEAK_GBS
-        except (OSError, ValueError):
-            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(s, nnz)
+    # ---- the other forms of the same config (rank 0, N = 1): the other row laws, and the collapsed (segment-level) form -----------
+    if rank == 0 and world == 1 and not args.no_variants and not args.collapsed and not args.merge_rows:
+        variants = {args.structure: {"ms_per_pass": kernel_ms / args.steps, "nnz": nnz, **_variant_stats(info),
+                                     "roofline_frac": out["roofline"]["frac"]}}
+        out["collapsed_form"] = collapsed_form(args, dev, s, info)
+        for st_name in ("window", "family", "family_shuffled"):
+            if st_name in variants:
+                continue
+            if st_name == "family_shuffled" and args.structure == "family":
+                v = shuffled_copy(s)                      # the same matrix, transcripts numbered at random
+            else:
+                v = synth.make_matrix(**_cfg(args, rank, st_name))
+            variants[st_name] = time_variant(args, dev, v, st_name)
+            del v
+        out["workload_variants"] = variants
     dev.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["fpkm_delta_vs_oracle"] = fpkm_delta_vs_oracle(local_rank, args.config)
+        out["fpkm_delta_vs_oracle"] = fpkm_delta_vs_oracle(local_rank, args.config, args.structure)
         out["time_to_mle"] = time_to_mle(local_rank)
     group.close()
     if rank == 0:
         print(json.dumps(out))
+
+
+def _variant_stats(info):
+    return {"tids_per_entry": info["tiled_ids"] / info["tiled_entries"] if info["tiled_entries"] else None,
+            "renumbered": info["renumbered"], "units": info["n_units"], "far_entries": info["far_entries"],
+            "stored_bytes_per_pass": info["stored_bytes_per_pass"]}
+
+
+def shuffled_copy(s):
+    import numpy as np
+    new_of_old = np.random.default_rng(12345).permutation(s["n_tx"]).astype(np.int32)
+    den = np.empty_like(s["den"])
+    den[new_of_old] = s["den"]
+    return {"n_tx": s["n_tx"], "n_reads": s["n_reads"], "row_ptr": s["row_ptr"], "col_idx": new_of_old[s["col_idx"]], "den": den}
+
+
+def time_variant(args, dev, v, name, passes=100):
+    """ms per pass of another row law of the same config (same kernel, same library defaults), 20 warm-up + `passes` timed passes."""
+    t0 = time.time()
+    dev.upload_structure(v["n_tx"], v["row_ptr"], v["col_idx"])
+    dev.upload_sample(None, None, v["den"])
+    t_up = time.time() - t0
+    info = dev.info()
+    dev.run_passes(20)
+    ms = dev.run_passes(passes) / passes
+    r = _roofline(args, name, info, ms / 1e3)
+    return {"ms_per_pass": ms, "nnz": int(len(v["col_idx"])), **_variant_stats(info), "upload_and_layout_s": round(t_up, 2),
+            "roofline_frac": r["frac"], "hbm_traffic_bytes": r["traffic"]}
+
+
+def collapsed_form(args, dev, s, info_read_level, passes=100):
+    """'also build the collapsed form (unique tid-sets + counts) and report both -- the collapsed form is what the reference
+    actually solves' (update_ReadCounts, emsar_functions.c:838-943; main.c:404).  The read-level matrix is collapsed on the device
+    (emsar_hip_collapse_rows), the segments and their read counts are uploaded as a weighted matrix and timed like the main workload."""
+    rp, ci, w, _, cst = dev.collapse_rows(s["n_tx"], s["row_ptr"], s["col_idx"], want_map=False)
+    t0 = time.time()
+    dev.upload_structure(s["n_tx"], rp, ci)
+    dev.upload_sample(w, None, s["den"])
+    t_up = time.time() - t0
+    info = dev.info()
+    dev.run_passes(20)
+    ms = dev.run_passes(passes) / passes
+    th = dev.get_theta()
+    mass = float((th * s["den"]).sum())
+    r = _roofline(args, args.structure, info, ms / 1e3, weighted=True, tag="+collapsed")
+    return {"rows": int(len(w)), "nnz": int(len(ci)), "reads": int(w.sum()), "ms_per_pass": ms, "iters_per_s": 1e3 / ms,
+            "collapse_kernel_ms": cst.kernel_ms, "upload_and_layout_s": round(t_up, 2), "kernel": r["kernel"],
+            "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_pass",
+                                           "stored_bytes_per_pass", "stored_GBps", "csr_equivalent_GBps")},
+            **_variant_stats(info), "mass_conserved": bool(abs(mass - s["n_reads"]) <= 1e-8 * s["n_reads"])}
 
 
 def cpu_baseline(s, nnz):
@@ -194,14 +313,14 @@ def cpu_baseline(s, nnz):
             "sample": "%d EM passes of the oracle's OpenMP EM over the same %d-read matrix (nnz %d)" % (n, s["n_reads"], nnz)}
 
 
-def fpkm_delta_vs_oracle(device, config):
+def fpkm_delta_vs_oracle(device, config, structure="family"):
     """BASELINE metric, last clause ('FPKM delta vs ref'): the benchmarked config, down-scaled until the CPU oracle solves it in
     seconds, solved by the HIP path and by the oracle's EM to the same tolerance; relative FPKM differences."""
     import numpy as np
     import oracle as O
     from emsar_amd import EmsarHip, synth
     scale = {"cfg2": 0.02, "cfg3": 0.004, "cfg4": 0.01, "cfg5": 0.0005}.get(config, 0.004)
-    s = synth.make_config(config, scale)
+    s = synth.make_config(config, scale, structure)
     m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
     cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), int(os.environ.get("EMSAR_CPU_THREADS", "16")))
     th_o, st_o = m.em_solve(max_iter=200000, accel=1, tol=1e-9, n_threads=cores)
@@ -211,7 +330,7 @@ def fpkm_delta_vs_oracle(device, config):
         th, st = dev.solve(max_iter=200000, accel=1, tol=1e-9, set_mode=1)
     big = th_o > 1e-3
     rel = np.abs(th - th_o)[big] / th_o[big]
-    return {"workload": "%s x %g: %d reads x %d transcripts" % (config, scale, s["n_reads"], s["n_tx"]), "tol": 1e-9,
+    return {"workload": "%s x %g (%s): %d reads x %d transcripts" % (config, scale, structure, s["n_reads"], s["n_tx"]), "tol": 1e-9,
             "max_rel_delta_fpkm_above_1e-3": float(rel.max()) if rel.size else 0.0, "max_abs_delta": float(np.abs(th - th_o).max()),
             "within_1e-5_rel_plus_1.5e-6": bool(np.all(np.abs(th - th_o) <= 1e-5 * np.abs(th_o) + 1.5e-6)),
             "loglik_gpu_minus_oracle": float(m.loglik(th) - m.loglik(th_o)), "gpu_passes": st.iters, "oracle_passes": st_o.iters}

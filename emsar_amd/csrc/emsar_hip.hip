@@ -135,6 +135,23 @@ inline void dfree(void *p) { if (p) (void)hipFree(p); }
 
 inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
 
+// The TILED layout may number the transcripts itself (renumber.hpp); every T-sized device vector is then in the LIBRARY's numbering and
+// the ABI maps: lib[new_of_old[t]] = caller[t].  Empty map = the caller's numbering.
+inline const std::vector<int32_t> &tid_map(const emsar_hip_ctx *ctx) { return ctx->TL.new_of_old; }
+inline const double *to_lib(const emsar_hip_ctx *ctx, const double *caller, std::vector<double> &tmp) {
+    const auto &m = tid_map(ctx);
+    if (m.empty() || ctx->layout != EMSAR_LAYOUT_TILED) return caller;
+    tmp.resize(m.size());
+    for (size_t t = 0; t < m.size(); t++) tmp[(size_t)m[t]] = caller[t];
+    return tmp.data();
+}
+inline void from_lib(const emsar_hip_ctx *ctx, double *v /* in place: library order -> caller order */) {
+    const auto &m = tid_map(ctx);
+    if (m.empty() || ctx->layout != EMSAR_LAYOUT_TILED) return;
+    std::vector<double> tmp(v, v + m.size());
+    for (size_t t = 0; t < m.size(); t++) v[t] = tmp[(size_t)m[t]];
+}
+
 // bytes one pass actually streams in the chosen layout: index arrays + row weights + the T-sized vectors
 inline int64_t stored_bytes(const emsar_hip_ctx *ctx) {
     int64_t rows = ctx->layout == EMSAR_LAYOUT_TILED ? ctx->n_slots + ctx->n_left : ctx->n_rows;
@@ -360,6 +377,18 @@ int ensure_sets_impl(emsar_hip_ctx *ctx) {
     try {
         emsar::build_sets(ctx->n_rows, ctx->n_tx, ctx->h_row_ptr.data(), ctx->h_col.data(), ctx->h_wgt.data(), S);
     } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
+    if (ctx->layout == EMSAR_LAYOUT_TILED && !tid_map(ctx).empty()) {
+        // the sets were found on the caller's CSR; theta / den on the device are in the library's numbering
+        const auto &m = tid_map(ctx);
+        try {
+            std::vector<uint8_t> kind(S.kind.size());
+            std::vector<double> usum(S.usum.size());
+            for (size_t t = 0; t < m.size(); t++) { kind[(size_t)m[t]] = S.kind[t]; usum[(size_t)m[t]] = S.usum[t]; }
+            S.kind.swap(kind); S.usum.swap(usum);
+        } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
+        for (int32_t &t : S.g_tid) t = m[(size_t)t];
+        for (int32_t &t : S.CL.g_tid) t = m[(size_t)t];
+    }
     auto up = [&](void **dp, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dp, std::max<size_t>(bytes, 16));
         if (e == hipSuccess && bytes) e = hipMemcpy(*dp, src, bytes, hipMemcpyHostToDevice);
@@ -753,6 +782,8 @@ int emsar_hip_upload_sample(emsar_hip_ctx *ctx, const int32_t *row_weight, const
         HIPCHK(hipMemcpy(ctx->d_wgt, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     }
     if (den) {
+        std::vector<double> tmp;
+        try { den = to_lib(ctx, den, tmp); } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
         HIPCHK(hipMemcpy(ctx->d_den, den, (size_t)ctx->n_tx * 8, hipMemcpyHostToDevice));
     } else {
         std::vector<double> ones;
@@ -780,6 +811,8 @@ int emsar_hip_set_theta(emsar_hip_ctx *ctx, const double *theta) {
     if (!ctx || !theta) return EMSAR_HIP_ERR_ARG;
     if (!ctx->have_sample) return EMSAR_HIP_ERR_STATE;
     HIPCHK(hipSetDevice(ctx->device));
+    std::vector<double> tmp;
+    try { theta = to_lib(ctx, theta, tmp); } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
     HIPCHK(hipMemcpyAsync(ctx->d_th[0], theta, (size_t)ctx->n_tx * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return EMSAR_HIP_OK;
@@ -791,6 +824,7 @@ int emsar_hip_get_theta(emsar_hip_ctx *ctx, double *theta) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(theta, ctx->d_th[0], (size_t)ctx->n_tx * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    try { from_lib(ctx, theta); } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
     return EMSAR_HIP_OK;
 }
 
@@ -912,6 +946,7 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
     HIPCHK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(fpkm_out, th[0], (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    try { from_lib(ctx, fpkm_out); } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
     ctx->count_floor = 0.0; ctx->zero_cut = 0.0;
     if (getenv("EMSAR_HIP_DEBUG"))
         fprintf(stderr, "emsar_hip_solve: %d streaming passes, %lld graph replays of %d cycles\n", iters, (long long)ctx->graph_launches, p.check_every);
@@ -976,6 +1011,7 @@ int emsar_hip_ieuma(emsar_hip_ctx *ctx, const double *row_L, double *ieuma_out) 
     int rc = scatter_rows(ctx, row_L, ctx->d_tmp[0]);
     if (rc) return rc;
     HIPCHK(hipMemcpy(ieuma_out, ctx->d_tmp[0], (size_t)ctx->n_tx * 8, hipMemcpyDeviceToHost));
+    try { from_lib(ctx, ieuma_out); } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }
     return EMSAR_HIP_OK;
 }
 
@@ -1051,6 +1087,8 @@ int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *o) {
     if (ctx->layout == EMSAR_LAYOUT_TILED) {
         o->n_chunks = ctx->n_tiles; o->n_slices = ctx->tl_n_fslices; o->padded_entries = ctx->tl_fwd_slots;
         o->far_entries = ctx->TL.far_entries; o->window = emsar::kTileDict;
+        o->tiled_entries = ctx->TL.tiled_entries; o->tiled_ids = ctx->TL.tiled_ids; o->renumbered = ctx->TL.renum.applied ? 1 : 0;
+        o->n_units = ctx->n_units;
     }
     o->bytes_per_pass = ctx->bytes_formula;
     o->stored_bytes_per_pass = stored_bytes(ctx);
@@ -1133,6 +1171,8 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
             info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 +
                                               (int64_t)L.far_tid.size() * 4 + (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4;
             info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
+            info_out->tiled_entries = L.tiled_entries; info_out->tiled_ids = L.tiled_ids; info_out->renumbered = L.renum.applied ? 1 : 0;
+            info_out->n_units = L.unit_first.empty() ? 0 : (int64_t)L.unit_first.size() - 1;
         }
         return rc == 0 ? EMSAR_HIP_OK : EMSAR_HIP_ERR_ARG - 100 + rc;
     } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }     // nothing may leave the C ABI as an exception

@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "layout.hpp"
+#include "renumber.hpp"
 
 namespace emsar {
 
@@ -166,7 +167,11 @@ struct TiledLayout {
     std::vector<uint64_t> left_ptr;
     std::vector<int32_t> left_col;
     std::vector<uint32_t> left_row;
-    int64_t tiled_entries = 0, far_entries = 0, coo_entries = 0, n_fslices = 0, padded_slots = 0;
+    int64_t tiled_entries = 0, far_entries = 0, coo_entries = 0, n_fslices = 0, padded_slots = 0, tiled_ids = 0;
+    // the library's transcript numbering (renumber.hpp): new_of_old[t] = id under which the caller's transcript t is stored; empty = the
+    // caller's numbering.  Everything in this structure (single_tid, far_tid, Tile::lo, left_col) is in the LIBRARY's numbering.
+    std::vector<int32_t> new_of_old;
+    RenumberStats renum;
     int64_t n_slots() const { return (int64_t)slot_row.size(); }
 };
 
@@ -272,11 +277,15 @@ inline int check_tiled_extents(const TiledLayout &L) {
 // (emsar_functions.c:838-943).  Every quantity the library computes is a sum over rows of a function of the row's tid
 // set times a per-row weight, so the merge is exact up to summation order.
 inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in, const int32_t *col_idx_in, TiledLayout &out,
-                       bool merge_rows = false) {
+                       bool merge_rows = false, bool renumber = true) {
     if (n_rows >= (int64_t)1 << 32) return -1;
     out = TiledLayout();
     const uint64_t *row_ptr = row_ptr_in;
     const int32_t *col_idx = col_idx_in;
+    if (renumber) cooccurrence_order(n_rows, n_tx, row_ptr_in, col_idx_in, kMaxRowLen, kBlk, out.new_of_old, out.renum);
+    // the id under which entry k of the caller's col_idx is stored
+    const int32_t *tid_map = out.new_of_old.empty() ? nullptr : out.new_of_old.data();
+    auto tid_at = [&](uint64_t k) -> int32_t { return tid_map ? tid_map[col_idx[k]] : col_idx[k]; };
     // merged view of the matrix (only built when asked for): unique rows with sorted tids
     std::vector<uint64_t> m_ptr;
     std::vector<int32_t> m_col;
@@ -287,7 +296,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         std::vector<uint64_t> hash((size_t)n_rows, 0);
         for (int64_t r = 0; r < n_rows; r++) {
             uint64_t b = row_ptr_in[r], e = row_ptr_in[r + 1];
-            std::copy(col_idx_in + b, col_idx_in + e, scol.begin() + (int64_t)b);
+            for (uint64_t k = b; k < e; k++) scol[(size_t)k] = tid_at(k);
             std::sort(scol.begin() + (int64_t)b, scol.begin() + (int64_t)e);
             uint64_t h = 1469598103934665603ull ^ (e - b);
             for (uint64_t k = b; k < e; k++) { h ^= (uint64_t)(uint32_t)scol[(size_t)k]; h *= 1099511628211ull; }
@@ -332,6 +341,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         out.merged = true;
         row_ptr = m_ptr.data();
         col_idx = m_col.data();
+        tid_map = nullptr;                      // the merged view is in the library's numbering already
         const int64_t n_rows_orig = n_rows;
         n_rows = n_m;
         out.n_rows = n_rows_orig; out.n_tx = n_tx; out.nnz = nnz_in;
@@ -373,7 +383,8 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         for (int64_t r = lo; r < hi; r++) {
             const uint64_t b = row_ptr[r], e = row_ptr[r + 1], len = e - b;
             if (len < 2 || len > (uint64_t)kMaxRowLen) continue;
-            tmp.assign(col_idx + b, col_idx + e);
+            tmp.resize((size_t)len);
+            for (uint64_t k = b; k < e; k++) tmp[(size_t)(k - b)] = tid_at(k);
             std::sort(tmp.begin(), tmp.end());
             mintid[(size_t)r] = anchor_median ? tmp[(size_t)(len / 2)] : tmp[0];
             int n_ent = 0, cur_b = -1;
@@ -397,10 +408,10 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 const uint64_t b = row_ptr[r], e = row_ptr[r + 1], len = e - b;
                 if (len == 0) continue;
                 const uint32_t r_orig = merge_rows ? orig_of_merged[(size_t)r] : (uint32_t)r;   // singles / long rows are never merged
-                if (len == 1) { P.single_row.push_back(r_orig); P.single_tid.push_back(col_idx[b]); continue; }
+                if (len == 1) { P.single_row.push_back(r_orig); P.single_tid.push_back(tid_at(b)); continue; }
                 if (len > (uint64_t)kMaxRowLen) {
                     P.left_row.push_back(r_orig);
-                    P.left_col.insert(P.left_col.end(), col_idx + b, col_idx + e);
+                    for (uint64_t k = b; k < e; k++) P.left_col.push_back(tid_at(k));
                     P.left_len.push_back(len);
                     continue;
                 }
@@ -513,7 +524,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 if (i1 > i0 && ents + (int64_t)(e - b) > (int64_t)unit_tiles * kTileEntries) break;
                 size_t before = distinct.size();
                 for (uint64_t k = b; k < e; k++) {
-                    int32_t t = col_idx[k];
+                    int32_t t = tid_at(k);
                     if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
                 }
                 if (i1 > i0 && (int64_t)distinct.size() > kTileDistinct) {   // undo this row, close the tile
@@ -535,7 +546,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 for (int64_t i = i0; i < i1; i++) {
                     uint32_t r = perm[(size_t)i];
                     for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
-                        int32_t t = col_idx[k];
+                        int32_t t = tid_at(k);
                         if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
                     }
                 }
@@ -569,7 +580,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 for (int64_t i = i0; i < i1; i++) {
                     uint32_t r = perm[(size_t)i];
                     for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
-                        int32_t t = col_idx[k];
+                        int32_t t = tid_at(k);
                         if (stamp[(size_t)t] != tile_id) { stamp[(size_t)t] = tile_id; distinct.push_back(t); }
                     }
                 }
@@ -601,7 +612,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 const uint32_t r = uord[(size_t)(i - i0)];
                 rslots.clear();
                 for (uint64_t q = row_ptr[r]; q < row_ptr[r + 1]; q++) {
-                    const int32_t d = loc[(size_t)col_idx[q]];
+                    const int32_t d = loc[(size_t)tid_at(q)];
                     rslots.push_back((uint32_t)d);
                     if (d >= near_n) out.far_entries++;
                 }
@@ -609,6 +620,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                 rent.insert(rent.end(), rents.begin(), rents.end());
                 rent_ptr.push_back((uint32_t)rent.size());
                 out.tiled_entries += (int64_t)rents.size();
+                out.tiled_ids += (int64_t)rslots.size();
             }
             // The rows of the unit (longest first) are cut into slices of 768; the slices are dealt to the four waves of the workgroup,
             // heaviest first, each to the wave with the least work so far (work = forward columns + entries: the first slice of a unit
@@ -782,7 +794,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             }
             out.coo.insert(out.coo.end(), F.coo.begin(), F.coo.end());
             out.far_tid.insert(out.far_tid.end(), F.far_tid.begin(), F.far_tid.end());
-            out.tiled_entries += F.tiled_entries; out.far_entries += F.far_entries; out.coo_entries += F.coo_entries;
+            out.tiled_entries += F.tiled_entries; out.tiled_ids += F.tiled_ids; out.far_entries += F.far_entries; out.coo_entries += F.coo_entries;
             out.n_fslices += F.n_fslices; out.padded_slots += F.padded_slots;
         }
         next.store(0);
@@ -875,8 +887,20 @@ inline int check_unit_tables(const TiledLayout &L, const UnitTables &U) {
 }
 
 // Decode and compare with the input (host self-check, used by the CPU tests). 0 = identical.
-inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int32_t *col_idx) {
+inline int check_tiled(const TiledLayout &L, const uint64_t *row_ptr, const int32_t *col_idx_in) {
     if (const int ext = check_tiled_extents(L)) return ext;          // the decode below indexes the arrays by the descriptors
+    // the layout is in the library's numbering: compare with the caller's rows mapped the same way (the map must be a permutation)
+    std::vector<int32_t> mapped;
+    const int32_t *col_idx = col_idx_in;
+    if (!L.new_of_old.empty()) {
+        if ((int64_t)L.new_of_old.size() != (int64_t)L.n_tx) return -11;
+        std::vector<uint8_t> hit((size_t)L.n_tx, 0);
+        for (int32_t v : L.new_of_old) { if (v < 0 || v >= L.n_tx || hit[(size_t)v]) return -11; hit[(size_t)v] = 1; }
+        const uint64_t nnz = row_ptr[L.n_rows];
+        mapped.resize((size_t)nnz);
+        for (uint64_t k = 0; k < nnz; k++) mapped[(size_t)k] = L.new_of_old[(size_t)col_idx_in[k]];
+        col_idx = mapped.data();
+    }
     std::vector<uint8_t> seen((size_t)L.n_rows, 0);
     for (size_t i = 0; i < L.single_row.size(); i++) {
         uint32_t r = L.single_row[i];

@@ -61,7 +61,8 @@ class Info(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("nnz", C.c_int64), ("n_tx", C.c_int32), ("layout", C.c_int32),
                 ("n_chunks", C.c_int64), ("n_slices", C.c_int64), ("padded_entries", C.c_int64),
                 ("far_entries", C.c_int64), ("window", C.c_int32), ("device_id", C.c_int32),
-                ("bytes_per_pass", C.c_int64), ("stored_bytes_per_pass", C.c_int64)]
+                ("bytes_per_pass", C.c_int64), ("stored_bytes_per_pass", C.c_int64),
+                ("tiled_entries", C.c_int64), ("tiled_ids", C.c_int64), ("n_units", C.c_int64), ("renumbered", C.c_int32), ("reserved0", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

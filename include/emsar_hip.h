@@ -207,6 +207,11 @@ typedef struct {
     int32_t device_id;
     int64_t bytes_per_pass;        /* SURVEY.md 8d formula */
     int64_t stored_bytes_per_pass; /* what the layout streams */
+    int64_t tiled_entries;         /* TILED: stored operands without padding (an operand = a block of 3 dictionary slots + a subset) */
+    int64_t tiled_ids;             /* TILED: transcript ids of the tiled rows; tiled_ids / tiled_entries = ids served per operand */
+    int64_t n_units;               /* TILED: workgroups of k_pass_tiled_unit (tiles that share a dictionary) */
+    int32_t renumbered;            /* TILED: 1 = the library numbered the transcripts by co-occurrence (theta / den are mapped at this ABI) */
+    int32_t reserved0;
 } emsar_hip_info;
 int emsar_hip_get_info(const emsar_hip_ctx *ctx, emsar_hip_info *out);
 

@@ -36,7 +36,7 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(H.EmParams) == 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 4 + 4
     assert C.sizeof(H.EmStats) == 4 + 4 + 8 * 4 + 8 * 2 + 4 * 4 + 8 * 3 + 4 + 4 + 8
     assert C.sizeof(H.SetsInfo) == 8 * 16
-    assert C.sizeof(H.Info) == 8 * 2 + 4 * 2 + 8 * 4 + 4 * 2 + 8 * 2
+    assert C.sizeof(H.Info) == 8 * 2 + 4 * 2 + 8 * 4 + 4 * 2 + 8 * 2 + 8 * 3 + 4 * 2
 
 
 def test_strerror(lib):
@@ -137,3 +137,33 @@ def test_tiled_layout_roundtrip_synthetic(lib):
     rp = np.zeros(len(rows) + 1, dtype=np.uint64)
     rp[1:] = np.cumsum([len(r) for r in rows])
     emsar_amd.layout_selfcheck_tiled(8, rp, np.concatenate(rows).astype(np.int32), True)
+
+
+@pytest.mark.parametrize("structure", synth.STRUCTURES)
+@pytest.mark.parametrize("mode", ["0", "1", "2"])      # never / decided by the sampled rows / always
+def test_renumbered_layout_roundtrip(lib, monkeypatch, structure, mode):
+    # the library's own transcript numbering (csrc/renumber.hpp): whatever it decides, the stored layout decodes to the caller's rows
+    # mapped through a permutation (check_tiled), with and without merged rows and with several builder fragments
+    monkeypatch.setenv("EMSAR_HIP_RENUMBER", mode)
+    monkeypatch.setenv("EMSAR_HIP_FRAG_ROWS", "6144")
+    monkeypatch.setenv("EMSAR_HOST_THREADS", "3")
+    m = synth.make_matrix(n_tx=6000, n_reads=120000, law="human", xfam=0.03, seed=17, structure=structure)
+    info = emsar_amd.layout_selfcheck_tiled(m["n_tx"], m["row_ptr"], m["col_idx"])
+    merged = emsar_amd.layout_selfcheck_tiled(m["n_tx"], m["row_ptr"], m["col_idx"], True)
+    assert info["renumbered"] == merged["renumbered"] == {"0": 0, "2": 1}.get(mode, info["renumbered"])
+    assert info["tiled_ids"] >= info["tiled_entries"] > 0
+
+
+def test_renumbering_recovers_shuffled_families(lib, monkeypatch):
+    # SURVEY 8d's family law with the transcripts numbered at random: the caller's tid order carries no information, a row needs one
+    # operand per hit; numbered by co-occurrence the same matrix packs as well as the unshuffled one
+    a = synth.make_matrix(n_tx=8000, n_reads=400000, law="human", xfam=0.02, seed=5, structure="family")
+    b = synth.make_matrix(n_tx=8000, n_reads=400000, law="human", xfam=0.02, seed=5, structure="family_shuffled")
+    per = {}
+    for name, m, mode in (("family", a, "1"), ("shuffled_off", b, "0"), ("shuffled", b, "1")):
+        monkeypatch.setenv("EMSAR_HIP_RENUMBER", mode)
+        i = emsar_amd.layout_selfcheck_tiled(m["n_tx"], m["row_ptr"], m["col_idx"])
+        per[name] = (i["tiled_ids"] / i["tiled_entries"], i["renumbered"], i["far_entries"])
+    assert per["shuffled_off"][0] < 1.05 and per["shuffled_off"][1] == 0
+    assert per["shuffled"][1] == 1 and per["shuffled"][0] > 0.95 * per["family"][0]
+    assert per["shuffled"][2] < 2 * per["family"][2] + 1000          # and the cross-family hits are the only far ones again

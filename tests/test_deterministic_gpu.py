@@ -21,8 +21,11 @@ def _solve(s, layout, det, **kw):
         return ctx.solve(set_mode=1, **kw)
 
 
-def test_two_solves_are_bit_identical():
-    s = synth.make_config("cfg3", 0.004)
+@pytest.mark.parametrize("structure", synth.STRUCTURES)
+def test_two_solves_are_bit_identical(structure, monkeypatch):
+    if structure == "family_shuffled":
+        monkeypatch.setenv("EMSAR_HIP_RENUMBER", "2")             # the library's own transcript numbering on
+    s = synth.make_config("cfg3", 0.004, structure)
     runs = [_solve(s, LAYOUT_TILED, True, max_iter=3000, accel=1, tol=1e-8) for _ in range(3)]
     th0, st0 = runs[0]
     assert st0.iters > 100 and (st0.converged == 1 or st0.iters >= 2990)
@@ -58,11 +61,14 @@ def test_passes_agree_across_kernels_to_the_fixed_point_resolution(monkeypatch):
         assert abs(out["tiled1"][1] - out[other][1]) <= 1e-11 * abs(out[other][1])
 
 
-@pytest.mark.parametrize("name,scale", [("cfg2", 0.05), ("cfg3", 0.004), ("cfg5", 0.0005)])
-def test_deterministic_passes_match_oracle(name, scale):
+@pytest.mark.parametrize("name,scale,structure", [("cfg2", 0.05, "window"), ("cfg3", 0.004, "window"), ("cfg5", 0.0005, "window"),
+                                                  ("cfg3", 0.004, "family"), ("cfg3", 0.004, "family_shuffled")])
+def test_deterministic_passes_match_oracle(name, scale, structure, monkeypatch):
     """Same EM map as the oracle's: after two passes every transcript's inferred reads agree to the fixed-point resolution, and
     the log-likelihood to 1e-10."""
-    s = synth.make_config(name, scale)
+    if structure == "family_shuffled":
+        monkeypatch.setenv("EMSAR_HIP_RENUMBER", "2")
+    s = synth.make_config(name, scale, structure)
     m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
     den = s["den"]
     want, _ = m.em_step(np.ones(s["n_tx"]), den, n_threads=4)

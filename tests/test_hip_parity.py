@@ -164,9 +164,16 @@ def test_non_finite_theta_is_reported_not_returned(set_mode):
         assert np.isfinite(th).all() and st.converged == 1
 
 
-@pytest.mark.parametrize("name,scale", [("cfg2", 0.05), ("cfg3", 0.004), ("cfg5", 0.0005)])
-def test_synthetic_read_level_matches_oracle(dev, name, scale):
-    s = synth.make_config(name, scale)                          # cfg5: heavy repeats, rows of 50-100 tids
+# the three row laws of emsar_amd/synth.py: consecutive-tid windows, SURVEY 8d's family subsets, and the same with the transcripts
+# numbered at random; renumber 2 = the library's own numbering (csrc/renumber.hpp) forced on, 0 = off, 1 = decided by the data
+@pytest.mark.parametrize("name,scale,structure,renumber", [
+    ("cfg2", 0.05, "window", "1"), ("cfg3", 0.004, "window", "1"), ("cfg5", 0.0005, "window", "1"),
+    ("cfg3", 0.004, "family", "1"), ("cfg3", 0.004, "family", "2"), ("cfg3", 0.004, "family_shuffled", "0"),
+    ("cfg3", 0.004, "family_shuffled", "2"), ("cfg3", 0.02, "family_shuffled", "1"), ("cfg3", 0.004, "window", "2"),
+    ("cfg5", 0.0005, "family_shuffled", "2"), ("cfg2", 0.05, "family", "2")])
+def test_synthetic_read_level_matches_oracle(dev, monkeypatch, name, scale, structure, renumber):
+    monkeypatch.setenv("EMSAR_HIP_RENUMBER", renumber)
+    s = synth.make_config(name, scale, structure)               # cfg5: heavy repeats, rows of 50-100 tids
     m = O.Csr(s["n_tx"], s["row_ptr"], s["col_idx"])
     den = s["den"]
     th0 = np.ones(s["n_tx"])
@@ -178,6 +185,21 @@ def test_synthetic_read_level_matches_oracle(dev, name, scale):
         dev.run_passes(2)
         got = dev.get_theta()
         assert np.all(np.abs(got - want2) <= 1e-11 * np.abs(want2) + 1e-300)
+        if layout != LAYOUT_CSR:
+            assert dev.info()["renumbered"] == {"0": 0, "2": 1}.get(renumber, dev.info()["renumbered"])
+    # the ABI speaks the caller's numbering whatever the library chose inside: set / get round trip, den, the per-transcript outputs
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
+    dev.upload_sample(None, None, None)                         # den computed on the device: E = 1 per row
+    dev.set_theta(want)
+    np.testing.assert_array_equal(dev.get_theta(), want)
+    dev.run_passes(1)
+    want_e1, _ = m.em_step(want, np.bincount(s["col_idx"], minlength=s["n_tx"]).astype(np.float64), n_threads=4)
+    got = dev.get_theta()
+    assert np.all(np.abs(got - want_e1) <= 1e-11 * np.abs(want_e1) + 1e-300)
+    L = np.random.default_rng(1).uniform(0.5, 2.0, size=s["n_reads"])
+    ie = dev.ieuma(L)
+    ie_want = np.bincount(s["col_idx"], weights=np.repeat(L, np.diff(s["row_ptr"].astype(np.int64))), minlength=s["n_tx"])
+    assert np.all(np.abs(ie - ie_want) <= 1e-10 * ie_want + 1e-300)
 
 
 def test_collapsed_and_read_level_agree(dev):
@@ -290,15 +312,21 @@ def _full_size_properties(dev, s, passes, csr_passes):
     return a
 
 
-def test_full_size_properties_cfg3(dev):
-    """BASELINE config 3 at full size (50M reads x 200k transcripts, nnz 251M): about 6 GiB of host arrays."""
+@pytest.mark.parametrize("structure", synth.STRUCTURES)
+def test_full_size_properties_cfg3(dev, structure):
+    """BASELINE config 3 at full size (50M reads x 200k transcripts, nnz 251M): about 6 GiB of host arrays.  On all three row laws:
+    the block-entry encoder's non-contiguous paths (one entry per hit, subsets with gaps, many far entries) at a size where tiles,
+    units and far lists fill, and the library's own numbering on the shuffled one."""
     if _avail_gib() < 24:
         pytest.skip("needs 24 GiB of free host memory")
-    s = synth.make_config("cfg3", 1.0)
-    _full_size_properties(dev, s, passes=4, csr_passes=3)
+    s = synth.make_config("cfg3", 1.0, structure)
+    _full_size_properties(dev, s, passes=4 if structure == "window" else 2, csr_passes=3 if structure == "window" else 2)
     # a solve to the bench's tolerance conserves the mass and lands where the merged-row layout lands
     dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], LAYOUT_TILED)
     dev.upload_sample(None, None, s["den"])
+    info = dev.info()
+    if structure == "family_shuffled":                               # numbered by co-occurrence, the shuffled matrix packs like the unshuffled one
+        assert info["renumbered"] == 1 and info["tiled_ids"] > 1.4 * info["tiled_entries"], info
     th, st = dev.solve(set_mode=1, max_iter=20000, accel=1, tol=1e-6, abs_floor=0.01, check_every=4)       # bench.py's solve_to_convergence
     assert st.converged == 1, (st.iters, st.final_delta)
     assert abs((th * s["den"]).sum() - s["n_reads"]) <= 1e-9 * s["n_reads"]
