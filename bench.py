@@ -59,6 +59,8 @@ def _kernel_name(info, weighted):
     if info["layout"] == 1:
         return "k_pass_csr"
     units = (multi == 5) or (multi == 1 and info["n_chunks"] > 2048)
+    if units and weighted:                # the plain EM pass of weighted rows runs the unit kernel too (likelihood passes: k_pass_tiled)
+        return "k_pass_tiled" if os.environ.get("EMSAR_HIP_WEIGHTED_UNIT", "1") == "0" else "k_pass_tiled_unit<weighted>"
     if units:
         return "k_pass_tiled_unit"
     if not weighted and multi in (2, 3, 4):

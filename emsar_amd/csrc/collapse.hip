@@ -528,6 +528,9 @@ extern "C" int emsar_hip_collapse_rows(emsar_hip_ctx *ctx, int64_t n_rows, int32
     CCHK(hipMemcpyAsync(&hc, d_cnt.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
     CCHK(hipStreamSynchronize(st));
     const int64_t nu = (int64_t)hc.n_claimed;
+    // every unique row has a member row, and every id of a unique row is an id of the input: anything else means the bookkeeping on the
+    // device went wrong -- say so instead of sizing copies by it
+    if (nu > n_rows) { emsar_internal_set_error(ctx, "collapse", "more unique rows than rows"); return EMSAR_HIP_ERR_HIP; }
     uint64_t nnz_u = 0;
     if (nu > 0) {
         // the slots in order of their first occurrence (the overflow lists are free now: sorted keys go there)
@@ -549,6 +552,7 @@ extern "C" int emsar_hip_collapse_rows(emsar_hip_ctx *ctx, int64_t n_rows, int32
         CCHK(hipMemcpyAsync(&last_len, d_ulen.as<uint64_t>() + (nu - 1), 8, hipMemcpyDeviceToHost, st));
         CCHK(hipStreamSynchronize(st));
         nnz_u = last_off + last_len;
+        if (nnz_u > nnz) { emsar_internal_set_error(ctx, "collapse", "unique rows hold more ids than the input"); return EMSAR_HIP_ERR_HIP; }
     }
     std::vector<long long> w64;
     try { w64.resize((size_t)nu); } catch (const std::bad_alloc &) { return EMSAR_HIP_ERR_OOM; }

@@ -95,6 +95,7 @@ struct emsar_hip_ctx {
     double *d_sqpart = nullptr;  // per-workgroup partial sums of the SQUAREM vector kernels [4][kSqPart]
     int update_grid = 1024;       // workgroups of k_update (EMSAR_HIP_UPDATE_GRID)
     int sq_grid = 256;           // workgroups of the SQUAREM vector kernels (EMSAR_HIP_SQ_GRID)
+    int weighted_unit = 1;       // EMSAR_HIP_WEIGHTED_UNIT: weighted rows on k_pass_tiled_unit -- 1: the plain EM pass, 2: the likelihood passes too, 0: never
     int tiled_multi = 1;         // EMSAR_HIP_TILED_MULTI 1: two tiles per workgroup (k_pass_tiled_multi) above kPairMinTiles tiles, else one
                                  // (k_pass_tiled); 2: always two; 0: always one
     const uint8_t *delta_mask = nullptr;   // d_kind while the streaming solve runs next to resident sets
@@ -229,6 +230,18 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
                 else if (ctx->tiled_multi == 3) { if (mode == MODE_EM_LL) LAUNCH_PN(false, MODE_EM_LL, 3); else LAUNCH_PN(false, MODE_EM, 3); }
                 else if (ctx->tiled_multi == 4) { if (mode == MODE_EM_LL) LAUNCH_PN(false, MODE_EM_LL, 4); else LAUNCH_PN(false, MODE_EM, 4); }
                 else if (mode == MODE_EM_LL) LAUNCH_P(false, MODE_EM_LL); else LAUNCH_P(false, MODE_EM);
+            }
+            else if (ctx->weighted && (ctx->weighted_unit == 2 || (ctx->weighted_unit == 1 && mode == MODE_EM)) &&
+                     (ctx->tiled_multi == 5 || (ctx->tiled_multi == 1 && ctx->n_tiles > kPairMinTiles))) {
+                // weighted rows (segments with read counts, merged rows) on the unit kernel: the weights are loaded as integers after the
+                // forward batch is consumed; both variants fit 128 VGPRs without scratch (round 3).  Measured on the collapsed form of
+                // config 3 (14.0 M segments of the family law / 5.4 M of the window law): plain pass 0.1273 -> 0.1221 / 0.0964 -> 0.0962 ms;
+                // the likelihood variant takes its twelve logs per lane in one rolled loop (tile_e_step) and is SLOWER than the one-tile
+                // kernel's unrolled logs (solve 0.161 against 0.150 ms per pass), so by default (1) only the plain EM pass of a SQUAREM
+                // cycle runs here and the two likelihood passes stay with k_pass_tiled; 2 = both, 0 = neither (EMSAR_HIP_WEIGHTED_UNIT)
+                hipLaunchKernelGGL((mode == MODE_EM_LL ? k_pass_tiled_unit<true, MODE_EM_LL> : k_pass_tiled_unit<true, MODE_EM>), dim3((unsigned)ctx->n_units), block, lds,
+                                   ctx->stream, ctx->d_utiles, ctx->unit_stride, ctx->d_far, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_wgt, theta, acc, ll_out,
+                                   fx_of(ctx, mode), (unsigned long long *)nullptr);
             }
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
             else { if (mode == MODE_EM_LL) LAUNCH_T(false, MODE_EM_LL); else LAUNCH_T(false, MODE_EM); }
@@ -650,7 +663,8 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
 #define SETLDS_P(WT, MD, NN) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_multi<WT, MD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             SETLDS_P(false, MODE_EM, 2); SETLDS_P(false, MODE_EM_LL, 2);
 #define SETLDS_U(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_unit<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-            SETLDS_U(false, MODE_EM); SETLDS_U(false, MODE_EM_LL);
+            SETLDS_U(false, MODE_EM); SETLDS_U(false, MODE_EM_LL); SETLDS_U(true, MODE_EM); SETLDS_U(true, MODE_EM_LL);
+            { const char *pe = getenv("EMSAR_HIP_WEIGHTED_UNIT"); ctx->weighted_unit = pe ? atoi(pe) : 1; }
 #undef SETLDS_U
             SETLDS_P(false, MODE_EM, 3); SETLDS_P(false, MODE_EM_LL, 3); SETLDS_P(false, MODE_EM, 4); SETLDS_P(false, MODE_EM_LL, 4);
 #undef SETLDS_P

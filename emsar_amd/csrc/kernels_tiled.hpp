@@ -510,6 +510,29 @@ __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], siz
         if (j0) load8_clamped(A, W.e + (size_t)j0 * 64, n0);
         fwd_sum_regs<EMSAR_UE_BATCH>(A, n0, th_base, S);
     }
+    if (WEIGHTED && MODE == MODE_EM_LL) {
+        // Weighted likelihood: sum r log S needs a log per row.  Twelve inlined f64 logs next to the weights and both index batches
+        // spilt registers (and made the unit kernel's likelihood variant slower than the one-tile kernel); here the row sums go through
+        // the wave's own w_s region (free until the weights are written) and ONE rolled loop holds the only copy of the log.
+#pragma unroll
+        for (int i = 0; i < kRPL; i++) w_s[64 * i + lane] = S[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        double acc = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < kRPL; i++) {
+            const double s = w_s[64 * i + lane];
+            const int ri = __builtin_nontemporal_load(&wgt[slot0 + 64 * i]);
+            const bool live = s > 0.0 && ri > 0;
+            const double rd = (double)ri;
+            w_s[64 * i + lane] = live ? rd / s : 0.0;
+            if (live) acc += rd * log(s);
+        }
+        ll.v += acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return;
+    }
     if (WEIGHTED) {
 #pragma unroll
         for (int i = 0; i < kRPL; i++) r[i] = __builtin_nontemporal_load(&wgt[slot0 + 64 * i]);

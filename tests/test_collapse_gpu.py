@@ -111,3 +111,23 @@ def test_full_hash_collisions_are_resolved_by_comparison(monkeypatch):
     for a, b in zip((got[0], got[1], got[2].astype(np.int64), got[3]), want):
         np.testing.assert_array_equal(a, b)
     assert len(got[2]) > 200                                       # many distinct multisets of equal length shared one chain
+
+
+def test_table_forced_too_small_with_long_rows_restarts(monkeypatch):
+    """The first table is sized by EMSAR_HIP_COLLAPSE_SHIFT (one slot per 2^shift rows; the knob is clamped to 0..8 and the table to
+    1024 slots: an unclamped value of 16 once made a table of 0 slots, i.e. a probe mask of all ones and a wild address -- DESIGN.md,
+    'the 14:08 memory fault of round 2').  At the largest shift on a matrix whose distinct segments outnumber the slots many times over,
+    with long rows (> 8 ids, the listed path) and short ones mixed, probe chains overrun in both insert kernels, the call starts over
+    with the worst-case table, and every output array is still the oracle's."""
+    monkeypatch.setenv("EMSAR_HIP_COLLAPSE_SHIFT", "8")
+    s = synth.make_config("cfg5", 0.002)                          # 400k reads, 20 ids per read on average, rows of 50-100 ids among them
+    with EmsarHip(0) as ctx:
+        got = ctx.collapse_rows(s["n_tx"], s["row_ptr"], s["col_idx"])
+        assert got[4].table_slots >= s["n_reads"]                 # the restart happened: the worst-case table went through
+        want = O.collapse_rows(s["row_ptr"], s["col_idx"])
+        for a, b in zip((got[0], got[1], got[2].astype(np.int64), got[3]), want):
+            np.testing.assert_array_equal(a, b)
+        monkeypatch.setenv("EMSAR_HIP_COLLAPSE_SHIFT", "16")       # out of range: ignored (the default applies), never a table of 0 slots
+        got = ctx.collapse_rows(s["n_tx"], s["row_ptr"], s["col_idx"])
+        for a, b in zip((got[0], got[1], got[2].astype(np.int64), got[3]), want):
+            np.testing.assert_array_equal(a, b)
