@@ -47,7 +47,7 @@ class EmStats(C.Structure):
 
 class CollapseStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("n_rows", C.c_int64), ("nnz", C.c_int64),
-                ("n_unique", C.c_int64), ("nnz_unique", C.c_int64), ("table_slots", C.c_int64), ("algorithmic_bytes", C.c_int64)]
+                ("n_unique", C.c_int64), ("nnz_unique", C.c_int64), ("table_slots", C.c_int64), ("algorithmic_bytes", C.c_int64), ("rounds", C.c_int64)]
 
 
 class SetsInfo(C.Structure):

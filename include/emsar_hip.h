@@ -178,8 +178,10 @@ int emsar_hip_adj_euma(emsar_hip_ctx *ctx, const double *wf /* nfl */, double *a
 typedef struct {
     double  kernel_ms;          /* device time of the collapse kernels (HIP events), transfers excluded */
     double  total_ms;           /* wall time of the call */
-    int64_t n_rows, nnz, n_unique, nnz_unique, table_slots;
+    int64_t n_rows, nnz, n_unique, nnz_unique;
+    int64_t table_slots;        /* LDS table slots over all partitions (one workgroup each) of the largest round */
     int64_t algorithmic_bytes;  /* CSR read twice (hash, compare) + weights + the unique rows written */
+    int64_t rounds;             /* 1 unless rows had to be hashed again (a 64-bit hash collision, a crowded partition table) */
 } emsar_hip_collapse_stats;
 int emsar_hip_collapse_rows(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr, const int32_t *col_idx,
                             const int32_t *row_weight, int64_t *n_unique_out, uint64_t *row_ptr_out, int32_t *col_idx_out,

@@ -90,8 +90,7 @@ def test_edge_cases_and_errors(dev):
 
 
 def test_mostly_unique_rows_outgrow_the_optimistic_table(dev):
-    """The table is sized for one segment per four reads first; when (nearly) every row is a segment of its own the probe
-    chains overrun, the call starts over with the worst-case table, and the result is the same."""
+    """(Nearly) every row is a segment of its own: the partition tables are sized by the RECORDS, so they hold them all."""
     rng = np.random.default_rng(5)
     n = 60000
     ci = rng.integers(0, 2 ** 20, size=3 * n).astype(np.int32)           # 3 random ids of a million per row: no two rows alike
@@ -113,21 +112,34 @@ def test_full_hash_collisions_are_resolved_by_comparison(monkeypatch):
     assert len(got[2]) > 200                                       # many distinct multisets of equal length shared one chain
 
 
-def test_table_forced_too_small_with_long_rows_restarts(monkeypatch):
-    """The first table is sized by EMSAR_HIP_COLLAPSE_SHIFT (one slot per 2^shift rows; the knob is clamped to 0..8 and the table to
-    1024 slots: an unclamped value of 16 once made a table of 0 slots, i.e. a probe mask of all ones and a wild address -- DESIGN.md,
-    'the 14:08 memory fault of round 2').  At the largest shift on a matrix whose distinct segments outnumber the slots many times over,
-    with long rows (> 8 ids, the listed path) and short ones mixed, probe chains overrun in both insert kernels, the call starts over
-    with the worst-case table, and every output array is still the oracle's."""
-    monkeypatch.setenv("EMSAR_HIP_COLLAPSE_SHIFT", "8")
-    s = synth.make_config("cfg5", 0.002)                          # 400k reads, 20 ids per read on average, rows of 50-100 ids among them
+def test_partitions_larger_than_their_table_overflow_into_further_rounds(monkeypatch):
+    """One workgroup counts one hash-prefix partition in an LDS table of 2048 slots; partitions are sized for ~1024 records, so the
+    table never fills.  EMSAR_HIP_COLLAPSE_PART_ROWS (test hook, clamped to [16, 2^20]: the partition count can never be 0 -- an
+    unclamped table-size knob once produced a table of 0 slots and a wild probe address, DESIGN.md 'the 14:08 memory fault of round
+    2') makes partitions of ~8192 records: keys that find no place within 64 probes of their home go to the overflow list and are
+    hashed again with the next seed, next to long rows (> 8 ids, the listed path), short rows and singles.  Every output array is
+    still the oracle's."""
+    monkeypatch.setenv("EMSAR_HIP_COLLAPSE_PART_ROWS", "8192")
+    rng = np.random.default_rng(7)
+    s = synth.make_config("cfg5", 0.0005)                         # 100k reads of 20 ids on average, rows of 50-100 ids among them, many duplicates
+    n_extra = 60000                                               # + rows that are nearly all segments of their own: 3 and 12 random ids of 2^20
+    e3 = rng.integers(0, 2 ** 20, size=(n_extra // 2, 3)).astype(np.int32)
+    e12 = rng.integers(0, 2 ** 20, size=(n_extra // 2, 12)).astype(np.int32)
+    ci = np.concatenate([s["col_idx"], e3.ravel(), e12.ravel()]).astype(np.int32)
+    lens = np.concatenate([np.diff(s["row_ptr"].astype(np.int64)), np.full(n_extra // 2, 3), np.full(n_extra // 2, 12)])
+    perm = rng.permutation(len(lens))                             # interleave the three kinds of rows
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    rp = np.zeros(len(lens) + 1, dtype=np.uint64)
+    rp[1:] = np.cumsum(lens[perm])
+    ci = np.concatenate([ci[starts[r]:starts[r] + lens[r]] for r in perm]).astype(np.int32)
+    want = O.collapse_rows(rp, ci)
     with EmsarHip(0) as ctx:
-        got = ctx.collapse_rows(s["n_tx"], s["row_ptr"], s["col_idx"])
-        assert got[4].table_slots >= s["n_reads"]                 # the restart happened: the worst-case table went through
-        want = O.collapse_rows(s["row_ptr"], s["col_idx"])
+        got = ctx.collapse_rows(2 ** 20, rp, ci)
+        assert got[4].rounds > 2                                    # the overflow rounds happened
         for a, b in zip((got[0], got[1], got[2].astype(np.int64), got[3]), want):
             np.testing.assert_array_equal(a, b)
-        monkeypatch.setenv("EMSAR_HIP_COLLAPSE_SHIFT", "16")       # out of range: ignored (the default applies), never a table of 0 slots
-        got = ctx.collapse_rows(s["n_tx"], s["row_ptr"], s["col_idx"])
+        monkeypatch.setenv("EMSAR_HIP_COLLAPSE_PART_ROWS", "0")        # out of range: ignored (the default applies)
+        got = ctx.collapse_rows(2 ** 20, rp, ci)
+        assert got[4].rounds == 1
         for a, b in zip((got[0], got[1], got[2].astype(np.int64), got[3]), want):
             np.testing.assert_array_equal(a, b)
