@@ -47,6 +47,7 @@ constexpr int64_t kPairMinTiles = 2048;   // 256 CUs x 4 resident workgroups x 2
 
 struct emsar_hip_ctx {
     int device = 0;
+    int n_cu = 64;               // compute units of the device (cluster launches: one workgroup per CU at most)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};     // the 256- and 512-thread classes of the set solver and the clusters run next to the 64-thread class
@@ -460,7 +461,7 @@ int ensure_sets_impl(emsar_hip_ctx *ctx) {
 }
 
 // closed-form transcripts and every LDS-resident set, written into theta (the streamed sets' entries are left alone)
-int solve_resident_sets(emsar_hip_ctx *ctx, const SetSolveParams &P, double *theta) {
+int solve_resident_sets(emsar_hip_ctx *ctx, const SetSolveParams &P, const SetSolveParams &Pcluster, double *theta) {
     const auto &S = ctx->RS;
     hipLaunchKernelGGL(k_closed_form, dim3(grid_for(ctx->n_tx, 256)), dim3(256), 0, ctx->stream, ctx->n_tx, ctx->d_kind, ctx->d_usum,
                        ctx->d_den, theta);
@@ -477,9 +478,7 @@ int solve_resident_sets(emsar_hip_ctx *ctx, const SetSolveParams &P, double *the
     if (ctx->n_cstat > 0) {
         // The clusters, on a stream of their own.  Every workgroup of a launch must be resident at once (they wait for each other at
         // the cluster barriers): at most one workgroup per CU per launch -- each asks for most of a CU's LDS --, whole sets only.
-        hipDeviceProp_t prop;
-        int n_cu = 64;
-        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        const int n_cu = ctx->n_cu;
         HIPCHK(hipMemsetAsync(ctx->d_cbar, 0, (size_t)ctx->n_cstat * 2 * sizeof(unsigned), ctx->side[2]));
         HIPCHK(hipEventRecord(ctx->ev_c0, ctx->side[2]));
         const auto &D = S.CL.desc;
@@ -489,7 +488,7 @@ int solve_resident_sets(emsar_hip_ctx *ctx, const SetSolveParams &P, double *the
             while (last < D.size() && (wgs == 0 || wgs + D[last].g <= (size_t)n_cu)) wgs += D[last++].g;
             hipLaunchKernelGGL(k_solve_cluster, dim3((unsigned)wgs), dim3(emsar::kClusterThreads), S.CL.max_lds, ctx->side[2], ctx->d_cdesc, ctx->d_cblk,
                                D[first].blk0, ctx->d_cg_tid, ctx->d_cg_u, ctx->d_crow_w, ctx->d_crp, ctx->d_cent, ctx->d_ccp, ctx->d_ccrow, ctx->d_cpart,
-                               ctx->d_cscratch, ctx->d_cbar, ctx->d_cbar + ctx->n_cstat, ctx->d_den, theta, ctx->d_cstat, P);
+                               ctx->d_cscratch, ctx->d_cbar, ctx->d_cbar + ctx->n_cstat, ctx->d_den, theta, ctx->d_cstat, Pcluster);
             first = last;
         }
         HIPCHK(hipEventRecord(ctx->ev_c1, ctx->side[2]));
@@ -543,6 +542,7 @@ int emsar_hip_create(emsar_hip_ctx **out, int device_id) {
     ctx->device = device_id;
     auto fail = [&](int rc) { emsar_hip_destroy(ctx); return rc; };
     if (hipSetDevice(device_id) != hipSuccess) return fail(EMSAR_HIP_ERR_NO_DEVICE);
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) ctx->n_cu = v; }
     if (const char *e = getenv("EMSAR_HIP_GRAPH")) ctx->use_graph = atoi(e) != 0;
     if (const char *e = getenv("EMSAR_HIP_DETERMINISTIC")) ctx->det = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(EMSAR_HIP_ERR_HIP);
@@ -945,7 +945,12 @@ static int solve_impl(emsar_hip_ctx *ctx, const emsar_em_params *pp, double *fpk
         const bool strict_sets = p.newton_after >= 0;
         SetSolveParams P{p.tol, p.abs_floor, p.count_floor, (!strict_sets && p.zero_cut > 0.0) ? p.zero_cut : 0.0,
                          (!strict_sets && p.abs_step > 0.0) ? p.abs_step : 0.0, p.max_iter, p.accel, p.newton_after == 0 ? 60 : p.newton_after};
-        if ((rc = solve_resident_sets(ctx, P, th[0]))) return rc;
+        // the cluster solver has no Newton step: its sets keep the two print-quantum rules whatever newton_after says (with the strict rule
+        // alone a boundary optimum keeps a cluster going for 10^5 passes at ~32 us each)
+        SetSolveParams Pc = P;
+        Pc.zero_cut = p.zero_cut > 0.0 ? p.zero_cut : 0.0;
+        Pc.abs_step = p.abs_step > 0.0 ? p.abs_step : 0.0;
+        if ((rc = solve_resident_sets(ctx, P, Pc, th[0]))) return rc;
         if (ctx->n_sstat > 0)
             HIPCHK(hipMemcpyAsync(ctx->h_sstat, ctx->d_sstat, (size_t)ctx->n_sstat * sizeof(SetStat), hipMemcpyDeviceToHost, ctx->stream));
         if (ctx->n_cstat > 0)

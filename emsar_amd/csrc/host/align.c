@@ -228,6 +228,8 @@ static int cmp_i32(const void *a, const void *b) { int32_t x = *(const int32_t *
 /* ---- read-level rows gathered for emsar_aln_opts.collapse ---------------------------------------------------------- */
 typedef struct { uint64_t *rp; int32_t *ci; int64_t n_rows, cap_rows; uint64_t nnz, cap_nnz; } row_batch;
 
+static pthread_mutex_t g_collapse_mu = PTHREAD_MUTEX_INITIALIZER;      /* serialises emsar_aln_opts.collapse (see batch_flush) */
+
 static void batch_free(row_batch *b) { if (b) { free(b->rp); free(b->ci); free(b); } }
 
 /* hand the gathered rows to the collapse function, look the unique rows up, add their weights (update_rshbucket 'r',
@@ -242,7 +244,13 @@ static int batch_flush(const emsar_rsh *r, const emsar_aln_opts *o, emsar_counts
     int32_t *w_o = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->n_rows);
     if (!rp_o || !ci_o || !w_o) rc = -1;
     b->rp[b->n_rows] = b->nnz;
-    if (!rc && o->collapse(o->collapse_user, b->n_rows, r->n_tx, b->rp, b->ci, &nu, rp_o, ci_o, w_o) != 0) rc = -2;
+    if (!rc) {
+        /* the parse workers flush their batches from their own threads: the callback (one device context, one stream, one set of
+         * buffers behind it) is entered by one thread at a time, whatever the caller passed */
+        pthread_mutex_lock(&g_collapse_mu);
+        if (o->collapse(o->collapse_user, b->n_rows, r->n_tx, b->rp, b->ci, &nu, rp_o, ci_o, w_o) != 0) rc = -2;
+        pthread_mutex_unlock(&g_collapse_mu);
+    }
     for (int64_t u = 0; !rc && u < nu; u++) {
         const int64_t row = emsar_rsh_row_of(r, ci_o + rp_o[u], (int)(rp_o[u + 1] - rp_o[u]));
         if (row >= 0) c->R[row] += w_o[u]; else c->reads_no_segment += w_o[u];

@@ -82,7 +82,9 @@ typedef struct {
     /* update_ReadCounts (emsar_functions.c:838-943) in two halves: the filters stay here, read by read; with `collapse` set, the
      * kept reads with two or more transcripts are not looked up one by one but gathered as read-level rows (sorted ids) and handed
      * to `collapse` in batches of `collapse_batch_rows`; only the UNIQUE rows that come back are looked up in the rsh, their
-     * weights added to ReadCount.  Same counts as the per-read path, by construction.  NULL = per-read lookup. */
+     * weights added to ReadCount.  Same counts as the per-read path, by construction.  NULL = per-read lookup.
+     * Threading: the ranged / batched parsers flush from their worker threads; the library serialises the calls (one at a time,
+     * process-wide), so the function need not be re-entrant -- but it may be entered from a thread other than the caller's. */
     emsar_collapse_fn collapse;
     void *collapse_user;
     int64_t collapse_batch_rows;     /* <= 0: 4M rows */

@@ -175,3 +175,43 @@ def test_rsh_ranges_keep_file_order_semantics(tmp_path, monkeypatch):
             HL.HostRsh(path2)
         msgs.append(str(e.value))
     assert msgs[0] == msgs[1] and "bad segment line" in msgs[0]
+
+
+def test_collapse_callback_is_never_entered_by_two_threads(tmp_path, monkeypatch):
+    """emsar_aln_opts.collapse is flushed by the parse workers from their own threads (a batch per worker).  The library serialises
+    the calls: a callback with one device context / one stream behind it (emsar_hip_collapse_rows through ctypes releases the GIL) is
+    entered by one thread at a time.  Here the callback sleeps with the GIL released and checks that it was alone; counts equal the
+    one-thread per-read path's."""
+    import gzip
+    import threading
+    import time
+    import oracle as O
+    case = get_fixture("syn2k_se").dir
+    r = HL.HostRsh(os.path.join(case, "index.rsh"))
+    src = os.path.join(case, "reads.bowtie.gz")
+    plain = str(tmp_path / "reads.bowtie")
+    with gzip.open(src, "rb") as f, open(plain, "wb") as g:
+        g.write(f.read())
+    monkeypatch.setenv("EMSAR_HOST_THREADS", "1")
+    want = r.count(plain, fmt=0)
+    inside = threading.Lock()
+    seen = {"calls": 0, "overlap": 0, "threads": set()}
+
+    def collapse(rp, ci):
+        if not inside.acquire(blocking=False):
+            seen["overlap"] += 1
+            inside.acquire()
+        try:
+            seen["calls"] += 1
+            seen["threads"].add(threading.get_ident())
+            time.sleep(0.002)                                             # GIL released: another worker could enter now
+            a, b, w, _ = O.collapse_rows(rp, ci)
+            return a, b, w
+        finally:
+            inside.release()
+
+    monkeypatch.setenv("EMSAR_HOST_THREADS", "6")
+    monkeypatch.setenv("EMSAR_HOST_RANGE_BYTES", "4096")
+    got = r.count(plain, fmt=0, collapse=collapse, collapse_batch_rows=50)
+    assert (got.R == want.R).all() and got.total_reads == want.total_reads and got.stats == want.stats
+    assert seen["calls"] > 6 and seen["overlap"] == 0

@@ -116,6 +116,28 @@ def test_cluster_solver_matches_the_streaming_solve_and_is_reproducible(monkeypa
              sb.iters, sb.kernel_ms, 1e3 * sb.kernel_ms / max(sb.iters, 1)))
 
 
+def test_cluster_sets_keep_the_print_quantum_rules_with_default_newton_steps(monkeypatch):
+    """The resident sets get Newton steps by default (newton_after >= 0) and are then held to the strict rule -- but the cluster solver
+    has no Newton step: its sets must keep zero_cut / abs_step, or a boundary optimum (theta -> 0 like 1/k) keeps a cluster going for
+    10^5 passes.  Boundary-optimum problem: a third of the transcripts of two large families have no reads of their own and share every
+    row with an expressed neighbour."""
+    n_tx, rp, ci, w = family_matrix([3000, 5000, 5], rows_per_tid=3, seed=5)
+    rng = np.random.default_rng(3)
+    E = rng.uniform(0.5, 2.0, size=len(w))
+    w = w.copy()
+    dead = rng.random(n_tx) < 0.33                       # rows that touch a 'dead' transcript only through multi-transcript rows lose their reads
+    touches = np.add.reduceat(dead[ci].astype(np.int64), rp[:-1].astype(np.int64)) > 0
+    w[touches & (np.diff(rp.astype(np.int64)) == 1)] = 0
+    monkeypatch.setenv("EMSAR_HIP_CLUSTER", "1")
+    with EmsarHip(0) as ctx:
+        ctx.upload_structure(n_tx, rp, ci, LAYOUT_TILED)
+        ctx.upload_sample(w, E, None)
+        th, st = ctx.solve(max_iter=200000, accel=1, tol=1e-10, set_mode=0, zero_cut=2.5e-7, abs_step=1e-13)     # newton_after default
+    assert st.sets_cluster == 2
+    assert st.converged == 1 and st.sets_unconverged == 0
+    assert st.cluster_passes_max < 100000, st.cluster_passes_max
+
+
 def test_closed_form_and_unweighted(dev):
     # every row has one transcript: theta = reads / den exactly, zero passes on any set
     rp = np.array([0, 1, 3, 4, 4], dtype=np.uint64)
