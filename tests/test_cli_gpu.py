@@ -255,3 +255,46 @@ def test_device_collapse_writes_the_same_files(case, tmp_path):
         assert open(outs[0] / ("out.0." + ext)).read() == open(outs[1] / ("out.0." + ext)).read()
     a, b = O.read_fpkm(str(outs[0] / "out.0.fpkm")), O.read_fpkm(str(outs[1] / "out.0.fpkm"))
     np.testing.assert_array_equal(a["fpkm"], b["fpkm"])
+
+
+def test_config4_shape_at_one_hundredth(tmp_path):
+    """BASELINE config 4 (-M: 8 single-end BAM samples of one index, one per GPU) at 1/100 of its size: 2000 transcripts in Zipf(1.6)
+    families, 8 x 200 000 reads written as BAM by tests/perf/synth_bam.c (tests/perf/cfg4_m.py runs the same at full size).  The list
+    run by four workers sharing the card (`--devices 0,0,0,0`) and by one worker must write the bytes the eight single-sample runs write
+    (`emsar_main.c:380-488`: samples are independent but for EUMAcut, which no set of this index raises), with and without the device
+    collapse; every sample conserves its reads; and the first sample agrees with the compiled reference where that is on the box."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "perf"))
+    import cfg4_gen as G
+    work = str(tmp_path)
+    idx = G.make_index(work, 2000)
+    bams = []
+    for i in range(8):
+        p = os.path.join(work, "s%d.bam" % i)
+        G.make_sample(idx, 200000, 40 + i, p, threads=4)
+        bams.append(p)
+    lst = os.path.join(work, "list.txt")
+    open(lst, "w").write("\n".join(bams) + "\n")
+    rsh = os.path.join(work, "index.rsh")
+    for tag, extra in (("w4", ["-M", "--devices", "0,0,0,0"]), ("w1", ["-M", "--devices", "0"]), ("w4c", ["-M", "--devices", "0,0,0,0", "--device-collapse"])):
+        subprocess.run([CLI, "-q", "-B"] + extra + ["-I", rsh, os.path.join(work, tag), "o", lst], check=True, timeout=600)
+    for i, b in enumerate(bams):
+        subprocess.run([CLI, "-q", "-B", "-I", rsh, os.path.join(work, "single%d" % i), "o", b], check=True, timeout=300)
+        want = open(os.path.join(work, "single%d" % i, "o.0.fpkm"), "rb").read()
+        for tag in ("w4", "w1", "w4c"):
+            assert open(os.path.join(work, tag, "o.%d.fpkm" % i), "rb").read() == want, (tag, i)
+        got = O.read_fpkm(os.path.join(work, "w4", "o.%d.fpkm" % i))
+        assert abs(got["ireadcount"].sum() - 200000) <= 1e-5 * 200000 + 1e-2 and abs(got["tpm"].sum() - 1e6) < 1.0
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "emsar")
+    if os.path.exists(ref):
+        runs = []
+        for k in range(3):                                              # SURVEY 8c: the mask needs k >= 3 reference runs
+            subprocess.run([ref, "-q", "-p", "4", "-B", "-I", rsh, os.path.join(work, "ref%d" % k), "o", bams[0]], check=True, timeout=600,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            runs.append(O.read_fpkm(os.path.join(work, "ref%d" % k, "o.0.fpkm"))["fpkm"])
+        a = np.array(runs)
+        mask = (a.max(0) - a.min(0)) > 1e-6 * np.abs(a).max(0) + 1.5e-6
+        got = O.read_fpkm(os.path.join(work, "w4", "o.0.fpkm"))["fpkm"]
+        bad = (np.abs(got - a[0]) > 1e-5 * np.abs(a[0]) + 1.5e-6) & ~mask
+        assert bad.sum() <= 2, (int(bad.sum()), np.nonzero(bad)[0][:5], got[bad][:5], a[0][bad][:5])
+        assert open(os.path.join(work, "w4", "o.0.fraglength_effect")).read() == open(os.path.join(work, "ref0", "o.0.fraglength_effect")).read()
