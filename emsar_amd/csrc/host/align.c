@@ -670,33 +670,48 @@ static int count_bam_parallel(const emsar_rsh *r, const char *path, const emsar_
     int malformed = 0;
     if (rc == EMSAR_HOST_OK) {
         bam_batch *cur = bam_batch_get(&P);
-        unsigned char prev[256]; size_t prev_n = 0; int have_prev = 0;
+        /* The stream is read into the batch buffer in large pieces (one memcpy per BGZF block instead of two calls per record) and
+         * hopped in place: per record the walk reads its length, refID, FLAG and -- only where a cut is possible, i.e. beyond
+         * batch_bytes -- compares its read name with the previous kept record's.  (Round 2 copied every record by itself and
+         * compared every name: 66 ns per record, 5.7 s for the 86 M records of a config-4 sample on ONE thread while the 16 workers
+         * and the GPU waited.) */
+        size_t fill = 0, at = 0;                                      /* bytes in cur->buf; start of the next record to hop over */
+        size_t prev_off = 0, prev_n = 0; int have_prev = 0;           /* read name of the previous kept record: offset in cur->buf */
+        int eof = 0;
         /* paired-end: the worker skips an unaligned record singly and reads an aligned one together with the record after
          * it (emsar_functions.c:514-520), so the pairs are known from refID alone; the first mate is held until the second
          * has shown whether the pair is kept */
         int have_r1 = 0; size_t r1_off = 0; int r1_flag = 0, r1_pos = 0, r1_ok = 0;
-        for (;;) {
-            unsigned char h[4];
-            long got = bam_get(bam, h, 4);
-            if (got == 0) break;
-            int32_t bs = got == 4 ? le32(h) : -1;
-            if (bs < 32 || bs > (1 << 28)) { malformed = 1; break; }
-            const size_t need = cur->n + 4 + (size_t)bs;
-            if (need > cur->cap) {
-                unsigned char *nb = (unsigned char *)realloc(cur->buf, need + (1 << 16));
-                if (!nb) { rc = EMSAR_HOST_ERR_OOM; break; }
-                cur->buf = nb; cur->cap = need + (1 << 16);
+        while (rc == EMSAR_HOST_OK && !malformed) {
+            /* a whole record at `at`?  else read on (the buffer grows for a record, or a read group, longer than its slack) */
+            int32_t bs = -1;
+            if (fill - at >= 4) {
+                bs = le32(cur->buf + at);
+                if (bs < 32 || bs > (1 << 28)) { malformed = 1; break; }
             }
-            unsigned char *rec = cur->buf + cur->n;
-            memcpy(rec, h, 4);
-            if (bam_rd(bam, rec + 4, (size_t)bs)) { malformed = 1; break; }
-            const unsigned char *q = rec + 4;
+            if (bs < 0 || fill - at < 4 + (size_t)bs) {
+                if (eof) { if (fill != at) malformed = 1; break; }
+                size_t want = batch_bytes + (1 << 15);
+                if (bs >= 0 && at + 4 + (size_t)bs > want) want = at + 4 + (size_t)bs;
+                if (fill >= want) want = fill + (1 << 16);
+                if (want > cur->cap) {
+                    unsigned char *nb = (unsigned char *)realloc(cur->buf, want + (1 << 16));
+                    if (!nb) { rc = EMSAR_HOST_ERR_OOM; break; }
+                    cur->buf = nb; cur->cap = want + (1 << 16);
+                }
+                const long got = bam_get(bam, cur->buf + fill, want - fill);
+                if (got < 0) { malformed = 1; break; }
+                if ((size_t)got < want - fill) eof = 1;
+                fill += (size_t)got;
+                continue;
+            }
+            const unsigned char *q = cur->buf + at + 4;
             const int32_t refid = le32(q), pos = le32(q + 4);
             const int l_name = q[8], flag = q[14] | (q[15] << 8);
             const int aligned = refid >= 0 && refid < bam->n_ref;
             const int name_ok = 32 + (size_t)l_name <= (size_t)bs && l_name >= 1;
-            size_t unit = cur->n;                                     /* where the record (or its pair) begins in the batch */
-            cur->n += 4 + (size_t)bs;
+            size_t unit = at;                                         /* where the record (or its pair) begins in the batch */
+            at += 4 + (size_t)bs;
             int kept;
             if (!o->pe) {
                 const char strand = (flag & 0x10) ? '-' : '+';
@@ -715,32 +730,36 @@ static int count_bam_parallel(const emsar_rsh *r, const char *path, const emsar_
                 else kept = !(o->strand == '+') && (s1 == '-' && s2 == '+');
                 kept = kept && grouped && r1_ok;
             }
-            if (kept) {
-                const unsigned char *nm = cur->buf + unit + 4 + 32;     /* read name of the record, or of the first mate */
-                const size_t nl = strnlen((const char *)nm, (size_t)cur->buf[unit + 4 + 8]);
-                const int new_group = !have_prev || nl != prev_n || memcmp(prev, nm, nl) != 0;
-                memcpy(prev, nm, nl); prev_n = nl; have_prev = 1;
-                if (new_group && unit >= batch_bytes) {               /* this record (pair) opens the next batch */
-                    const size_t moved = cur->n - unit;
+            if (!kept) continue;
+            const size_t nm_off = unit + 4 + 32;                       /* read name of the record, or of the first mate */
+            const size_t nl = strnlen((const char *)cur->buf + nm_off, (size_t)cur->buf[unit + 4 + 8]);
+            if (unit >= batch_bytes) {                                /* a cut is possible here: does this record (pair) open a new read group? */
+                const int new_group = !have_prev || nl != prev_n || memcmp(cur->buf + prev_off, cur->buf + nm_off, nl) != 0;
+                if (new_group) {                                      /* it opens the next batch: the tail of the buffer moves there */
+                    const size_t moved = fill - unit;
                     bam_batch *nb = bam_batch_get(&P);
-                    if (moved > nb->cap) {
-                        unsigned char *g = (unsigned char *)realloc(nb->buf, moved + (1 << 16));
+                    if (moved + (1 << 16) > nb->cap) {
+                        unsigned char *g = (unsigned char *)realloc(nb->buf, moved + (1 << 17));
                         if (!g) { bam_batch_put(&P, nb); rc = EMSAR_HOST_ERR_OOM; break; }
-                        nb->buf = g; nb->cap = moved + (1 << 16);
+                        nb->buf = g; nb->cap = moved + (1 << 17);
                     }
                     memcpy(nb->buf, cur->buf + unit, moved);
-                    nb->n = moved;
                     cur->n = unit;
                     cur->index = n_batches++;
                     bam_batch_put(&P, cur);
                     cur = nb;
+                    fill = moved; at -= unit;
+                    prev_off = nm_off - unit; prev_n = nl; have_prev = 1;
                     pthread_mutex_lock(&P.mu);
                     const int failed = P.rc != EMSAR_HOST_OK;
                     pthread_mutex_unlock(&P.mu);
-                    if (failed) { cur->n = 0; break; }                /* a batch already failed: whatever follows cannot come first */
+                    if (failed) { fill = at = 0; break; }             /* a batch already failed: whatever follows cannot come first */
+                    continue;
                 }
             }
+            prev_off = nm_off; prev_n = nl; have_prev = 1;
         }
+        cur->n = (rc == EMSAR_HOST_OK && !malformed) ? fill : 0;       /* (an unpaired first mate at the end of the file stays in: the worker's loop decides, as before) */
         cur->index = n_batches++;
         bam_batch_put(&P, cur);                                       /* the last batch (possibly empty) */
     }
