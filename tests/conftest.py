@@ -10,7 +10,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["toy5_se50", "toy5_sam", "toy5_bam", "toy5_pe", "toy5_pe_sam", "toy5_pe_bam", "syn300_se", "syn300_k2", "syn2k_se"]
+CASES = ["vicugna_pe", "toy5_se50", "toy5_sam", "toy5_bam", "toy5_pe", "toy5_pe_sam", "toy5_pe_bam", "syn300_se", "syn300_k2", "syn2k_se"]
 
 
 def pytest_configure(config):

@@ -405,7 +405,94 @@ def case_toy5_pe(case_dir, sam=False, bam=False):
     return {"n_reads_emitted": n_reads, "total_read_count": None, "opts": opts, "cmd": " ".join(cmd)}
 
 
+# ----------------------------------------------------------------------------------------------
+# BASELINE config 1 stand-in: the bundled Vicugna BAM + rsh are absent from the checkout, so a Vicugna-SHAPED case:
+# the 12 704 transcript names and the gene column of samples/Vicugna_pacos.vicPac1.72.cdna.all.g2t, random sequences in which the
+# transcripts of a gene (and ~200 made-up paralog groups) share an exon block, paired-end L = 101, fragments 290-300, 100 000 pairs,
+# through the real `emsar-build --PE -f 290 -F 300` and the real `emsar -P`.
+# ----------------------------------------------------------------------------------------------
+VICUGNA_G2T = "/root/reference/samples/Vicugna_pacos.vicPac1.72.cdna.all.g2t"
+
+
+def case_vicugna_pe(case_dir, n_pairs=100000):
+    rng = random.Random(72)
+    L, fmin, fmax = 101, 290, 300
+    names, genes = [], {}
+    for line in open(VICUGNA_G2T):
+        g, t = line.split()
+        genes.setdefault(g, []).append(len(names))
+        names.append(t)
+    n_tx = len(names)
+    groups = [m for m in genes.values() if len(m) > 1]                      # 37 genes with 2-3 transcripts
+    lone = [m[0] for m in genes.values() if len(m) == 1]
+    rng.shuffle(lone)
+    k = 0
+    for _ in range(200):                                                    # paralog groups among the single-transcript genes
+        n = rng.choice([2, 2, 2, 3, 3, 4])
+        groups.append(lone[k:k + n])
+        k += n
+    seq = [None] * n_tx
+    share = {}                # tid -> (group id, offset of the block in the transcript, length of the block the transcript carries)
+    blocks = []
+    for gid, mem in enumerate(groups):
+        blen = rng.randint(330, 460)
+        block = rand_seq(rng, blen)
+        blocks.append(block)
+        for j, t in enumerate(mem):
+            have = blen if (j == 0 or rng.random() < 0.7) else rng.randint(300, blen)      # some members carry a prefix of the block only
+            left, right = rand_seq(rng, rng.randint(0, 160)), rand_seq(rng, rng.randint(0, 160))
+            seq[t] = left + block[:have] + right
+            share[t] = (gid, len(left), have)
+    for t in range(n_tx):
+        if seq[t] is None:
+            seq[t] = rand_seq(rng, rng.randint(320, 620))
+    fa = os.path.join(case_dir, "tx.fa")
+    with open(fa, "w") as f:
+        for n, s_ in zip(names, seq):
+            f.write(">%s\n%s\n" % (n, s_))
+    t0 = time.time()
+    subprocess.run([REF_BUILD, "-q", "--PE", "-f", str(fmin), "-F", str(fmax), fa, str(L), case_dir, "index"], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    print("  emsar-build --PE: %.1fs" % (time.time() - t0))
+    os.remove(fa)                                                            # 6 MB of random sequence: reproducible from the seed, not stored
+    for f in os.listdir(case_dir):
+        if f.startswith("index.") and f != "index.rsh":
+            os.remove(os.path.join(case_dir, f))
+    # abundances: log-normal, 30 % silent; a fragment = (transcript, start, length)
+    theta = [0.0 if rng.random() < 0.3 else rng.lognormvariate(0, 2) for _ in range(n_tx)]
+    tw = [theta[t] * max(0, len(seq[t]) - fmax + 1) for t in range(n_tx)]
+    picks = rng.choices(range(n_tx), tw, k=n_pairs)
+    by_gid = {}
+    for t, (gid, off, have) in share.items():
+        by_gid.setdefault(gid, []).append((t, off, have))
+    lines = []
+    for i, t in enumerate(picks):
+        fl = rng.randint(fmin, fmax)
+        p0 = rng.randint(0, len(seq[t]) - fl)
+        hits = [(t, p0)]
+        if t in share:                        # both mates inside the shared block: the pair maps to every member that carries that stretch
+            gid, off, have = share[t]
+            x = p0 - off                      # block coordinate of the fragment start
+            if x >= 0 and x + fl <= have:
+                hits = [(u, uoff + x) for (u, uoff, uhave) in sorted(by_gid[gid]) if x + fl <= uhave]
+        flip = (i % 2 == 1)                   # the fragment came from the other strand: mate 1 is the reverse read
+        for (h, q1) in hits:
+            a, b = ("+", q1), ("-", q1 + fl - L)
+            first, second = (a, b) if not flip else (b, a)
+            lines.append("p%d/1\t%s\t%s\t%d\t%s\t%s\t0\t\n" % (i, first[0], names[h], first[1], "A" * L, "I" * L))
+            lines.append("p%d/2\t%s\t%s\t%d\t%s\t%s\t0\t\n" % (i, second[0], names[h], second[1], "A" * L, "I" * L))
+    aln = os.path.join(case_dir, "reads.bowtie")
+    with open(aln, "w") as f:
+        f.writelines(lines)
+    opts = ["-P", "-p", "4"]
+    cmd = run_reference(case_dir, os.path.join(case_dir, "index.rsh"), aln, opts)
+    gzip_inplace(aln)
+    return {"n_reads_emitted": n_pairs, "total_read_count": None, "opts": opts, "cmd": " ".join(cmd),
+            "note": "Vicugna-shaped stand-in for BASELINE config 1 (bundled BAM / rsh absent): names and genes of the .g2t, synthetic sequences"}
+
+
 CASES = {
+    "vicugna_pe": case_vicugna_pe,
     "toy5_se50": case_toy5,
     "toy5_sam": case_toy5_sam,
     "toy5_pe": case_toy5_pe,
