@@ -372,14 +372,28 @@ def time_to_mle(device):
     t0 = time.perf_counter()
     th_q, st_q = dev.solve(max_iter=200000, tol=1e-10, zero_cut=2.5e-7, abs_step=1e-13)
     gpu_q_s = time.perf_counter() - t0
+    # time to EQUAL likelihood: the pattern search stops short of the optimum on large families (loglik_gpu_minus_cpu > 0), so 'time to
+    # the MLE' compares two different end points; this is the time emsar_hip_solve needs to reach the likelihood the CPU run ended at
+    F_ref = m.loglik(th_ref)
+    equal_F = None
+    for tol_e in (1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 1e-8, 1e-10):
+        t0 = time.perf_counter()
+        th_e, st_e = dev.solve(max_iter=200000, tol=tol_e)
+        dt_e = time.perf_counter() - t0
+        if m.loglik(th_e) >= F_ref:
+            equal_F = {"tol": tol_e, "gpu_s": dt_e, "gpu_em_passes_slowest_set": st_e.set_passes_max, "speedup": cpu_s / dt_e,
+                       "loglik_gpu_minus_cpu": m.loglik(th_e) - F_ref}
+            break
     dev.close()
-    F_ref, F = m.loglik(th_ref), m.loglik(th)
+    F = m.loglik(th)
     return {"workload": "segment-level synthetic: %d transcripts in %d families (Zipf 1.6, <= 60), %d segments, %d reads, %d connected sets"
                         % (n_tx, len(sizes), len(R), int(R.sum()), n_sets),
             "gpu_s": gpu_s, "gpu_kernel_ms": st.kernel_ms, "gpu_em_passes_slowest_set": st.set_passes_max, "gpu_sets_resident": st.sets_resident,
             "gpu_sets_streamed": st.sets_streamed, "gpu_converged": bool(st.converged), "set_packing_host_ms": st.sets_build_ms,
             "cpu_reference_algorithm_s": cpu_s, "cpu_cores": cores, "cpu_kind": "port", "cpu_sweeps": int(sweeps),
-            "speedup": cpu_s / gpu_s, "loglik_gpu_minus_cpu": F - F_ref, "loglik": F,
+            "speedup": cpu_s / gpu_s, "loglik_gpu_minus_cpu": F - F_ref, "loglik": F, "time_to_equal_loglik": equal_F,
+            "note": "cpu_kind port = the oracle's restatement of the reference's pattern search; the same-box whole-program comparison against the "
+                    "compiled reference is profiles/r03_ref_vs_hip_sets_100k.txt (tests/perf/ref_vs_hip.py)",
             "print_quantum_stop": {"zero_cut": 2.5e-7, "abs_step": 1e-13, "gpu_s": gpu_q_s, "gpu_em_passes_slowest_set": st_q.set_passes_max,
                                    "max_abs_dtheta_vs_strict": float(np.abs(th_q - th).max()),
                                    "printed_differently": int((np.round(th_q, 6) != np.round(th, 6)).sum()), "speedup": cpu_s / gpu_q_s}}
