@@ -435,11 +435,16 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     const int64_t n_act = (int64_t)act.size();
     // Sort granularity in tid space.  A tile's dictionary must hold a block's tid range plus the rows' reach, so
     // blocks stay small; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
-    int32_t block = 128;       // the rows of one block of the sort fit one dictionary (360 transcripts) with room for their far hits;
+    int32_t block = 48;        // round 3: 16 / 24 / 32 / 48 / 64 / 96 / 128 -> family law 0.1122 / 0.1126 / 0.1128 / 0.1141 / 0.1152 / 0.1205 / 0.1236,
+                               // window law 0.1017 / 0.1012 / 0.1015 / 0.1015 / 0.1024 / 0.1042 / 0.1059, config 5 x 0.25 - / - / 0.2469 / 0.2376 / 0.2439 /
+                               // 0.2442 / 0.2456 ms per pass (gpurun_out/sweep2,3): narrow blocks close FEWER units (4.4 k instead of 5.2-5.4 k on config 3 --
+                               // the rows of a unit share more of their transcripts) although the slices are less uniform (more padding, more stored
+                               // bytes): per-unit latency, not bytes, is what the pass pays for.  Before (rounds 1-2, 128):
+                               // the rows of one block of the sort fit one dictionary (360 transcripts) with room for their far hits;
                                // config 3, rows sorted by entry count inside a block: 96 / 128 / 160 / 192 tids -> 0.1178 / 0.1169 / 0.1187 / 0.124 ms per pass
                                // end of round 2 (spill-free unit kernel): 96 / 104 / 112 / 120 / 128 / 144 / 160 -> 0.1052 / 0.1056 / 0.1055 / 0.1066 / 0.1063 /
                                // 0.1072 / 0.1067 on config 3, but config 5 (20 transcripts per read) 0.954 ms at 112 against 0.940 at 128: stays 128
-    if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 900) block = v; }
+    if (const char *e = getenv("EMSAR_HIP_TILE_BLOCK")) { int v = atoi(e); if (v >= 16 && v <= 900) block = v; }
     int short_ecnt = 0; int32_t short_block = 512;      // rows of <= short_ecnt entries: sort block short_block (0 = no such class)
     if (const char *e = getenv("EMSAR_HIP_SHORT_ECNT")) { int v = atoi(e); if (v >= 0 && v <= 32) short_ecnt = v; }
     if (const char *e = getenv("EMSAR_HIP_SHORT_BLOCK")) { int v = atoi(e); if (v >= block && v <= (1 << 20)) short_block = v; }

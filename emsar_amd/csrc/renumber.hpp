@@ -34,7 +34,8 @@ struct RenumberStats {
 };
 
 constexpr int kRenumberCap = 128;          // transcripts per cluster at most (the sort block of build_tiled; a dictionary holds 360)
-constexpr int64_t kRenumberMaxPairs = (int64_t)48 << 20;   // sampled pairs at most (the table stays below 1.6 GB)
+constexpr int64_t kRenumberMaxPairs = (int64_t)12 << 20;   // sampled pairs at most: config 3 at 48 M pairs spent 3 s here on one thread, at 12 M 0.8 s with the
+                                                           // same clusters on the shuffled family law (a pair is kept from two sightings on)
 
 // block entries of one sorted row under a numbering (the rule of layout_tiled.hpp: slots_to_entries on tids), blk slots per block
 inline int row_entries(const int32_t *ids, int n, int blk) {

@@ -1,0 +1,37 @@
+# layout knobs swept on the family law of config 3 (they were tuned on the window law in rounds 1-2); one line per setting
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-sweep}; mkdir -p $O; cd $R
+python - <<'PY' > $O/sweep.txt 2>&1
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+from emsar_amd import EmsarHip, synth
+s = synth.make_config("cfg3", 1.0, "family")
+dev = EmsarHip(0)
+def run(env):
+    for k in ("EMSAR_HIP_TILE_BLOCK", "EMSAR_HIP_UNIT_TILES", "EMSAR_HIP_TILE_ROWS", "EMSAR_HIP_RENUMBER", "EMSAR_HIP_SHORT_ECNT", "EMSAR_HIP_SHORT_BLOCK"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    os.environ.setdefault("EMSAR_HIP_RENUMBER", "0")
+    dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"])
+    dev.upload_sample(None, None, s["den"])
+    i = dev.info()
+    dev.run_passes(200)
+    ms = min(dev.run_passes(200) / 200 for _ in range(3))
+    print(env, "ms/pass %.4f" % ms, "units", i["n_units"], "tiles", i["n_chunks"], "padded", i["padded_entries"], "entries", i["tiled_entries"], "far", i["far_entries"],
+          "stored MB %.1f" % (i["stored_bytes_per_pass"] / 1e6), flush=True)
+for b in ("16", "24", "32"):
+    run({"EMSAR_HIP_TILE_BLOCK": b})
+s = synth.make_config("cfg3", 1.0, "window")
+print("window law", flush=True)
+for b in ("16", "24", "32", "48"):
+    run({"EMSAR_HIP_TILE_BLOCK": b})
+s = synth.make_config("cfg5", 0.25, "window")
+print("cfg5 x 0.25", flush=True)
+for b in ("32", "48", "64", "96", "128"):
+    run({"EMSAR_HIP_TILE_BLOCK": b})
+s = synth.make_config("cfg2", 1.0, "window")
+print("cfg2", flush=True)
+for b in ("32", "48", "64", "128"):
+    run({"EMSAR_HIP_TILE_BLOCK": b})
+PY
+cat $O/sweep.txt
