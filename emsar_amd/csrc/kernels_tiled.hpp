@@ -128,8 +128,8 @@ __device__ __forceinline__ void tile_acc_add(double *acc_w, unsigned off, double
 // entry is flushed by the thread that fetched it.
 struct BlockDict { double th[kBlk]; int tid[kBlk]; int stid[2]; };     // stid: the transcripts of near SLOTS threadIdx.x and threadIdx.x + 256
 constexpr int kSlotsPerThread = (emsar::kTileDict + kTiledThreads - 1) / kTiledThreads;
-static_assert(kSlotsPerThread == 2, "BlockDict::stid");
-static_assert(emsar::kFarMax == kBlk * (kTiledThreads - emsar::kDictBlocks), "three far entries per thread that owns no near block");
+static_assert(kSlotsPerThread <= 2, "BlockDict::stid");
+static_assert(emsar::kFarMax <= kBlk * (kTiledThreads - emsar::kDictBlocks), "kBlk far entries per thread that owns no near block");
 // the far list of a unit (n transcripts at far), three per thread that owns no near block
 __device__ __forceinline__ void block_dict_far_issue(const int32_t *far, int n, BlockDict &D) {
 #pragma unroll

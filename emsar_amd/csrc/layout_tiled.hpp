@@ -55,11 +55,16 @@ constexpr int kTileRows = kTileSlices * kTileSliceRows;
 // gathers for the same matrix.  The M-step accumulates per entry value and folds the 8 words of a block into its 3 transcripts
 // when the tile is flushed.  Entry 0 (block 0, empty subset) is the padding: T[0] = 0.
 #ifndef EMSAR_BLK
-#define EMSAR_BLK 3
+#define EMSAR_BLK 4
 #endif
 constexpr int kBlk = EMSAR_BLK;                  // slots per block (3: 120 blocks x 8 sums; 4: 60 blocks x 16 sums -- both 960 table entries).
-                                                 // Measured on config 3: 4 packs 3.1 tids per entry instead of 2.5, but a tile then holds 240
-                                                 // transcripts instead of 360 and there are 10.9 k tiles instead of 8.8 k: 0.140 against 0.117 ms
+                                                 // Round 2 (sort block 128): 4 packs 3.1 tids per entry instead of 2.5, but a tile then holds 240
+                                                 // transcripts instead of 360 and there were 10.9 k tiles instead of 8.8 k: 0.140 against 0.117 ms.
+                                                 // Round 3: with the narrow sort block (32-48 tids) a unit's rows fit 240 transcripts, and 4 wins on
+                                                 // everything large -- config 3 family law 0.1150 -> 0.1060 ms (1.59 -> 1.82 ids per entry, 4616 ->
+                                                 // 3517 units, 486 -> 443 MB), window law 0.1017 -> 0.0969 (2.51 -> 2.95, 382 -> 340 MB), config 5
+                                                 // x 0.25 0.2463 -> 0.2195 (1147 -> 926 MB); config 2 (705 units, latency-bound) 0.0190 -> 0.0208.
+                                                 // 5 slots (32 sums, 150 transcripts per dictionary): far entries x 6, 51 MB instead of 44 at 1/10 size
 constexpr int kBlkEntries = 1 << kBlk;           // subset sums per block
 constexpr int kDictBlocks = 960 / kBlkEntries;
 constexpr int kDictEntries = kDictBlocks * kBlkEntries;   // 960 doubles of LDS for T, 960 for the per-entry accumulators
@@ -435,7 +440,9 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     const int64_t n_act = (int64_t)act.size();
     // Sort granularity in tid space.  A tile's dictionary must hold a block's tid range plus the rows' reach, so
     // blocks stay small; wide blocks keep the (block, length) buckets large, i.e. the slices uniform.
-    int32_t block = 48;        // round 3: 16 / 24 / 32 / 48 / 64 / 96 / 128 -> family law 0.1122 / 0.1126 / 0.1128 / 0.1141 / 0.1152 / 0.1205 / 0.1236,
+    int32_t block = 32;        // with 4-slot blocks (kBlk): 24 / 32 / 48 / 64 / 96 -> family law 0.1063 / 0.1060 / 0.1071 / 0.1089 / 0.1146, window law 0.0967 /
+                               // 0.0969 / 0.0980 / 0.1030 / 0.1014, config 5 x 0.25 - / 0.2195 / 0.2204 / 0.2192 / 0.2216 ms (gpurun_out/sweep_blk4).
+                               // With 3-slot blocks: 16 / 24 / 32 / 48 / 64 / 96 / 128 -> family law 0.1122 / 0.1126 / 0.1128 / 0.1141 / 0.1152 / 0.1205 / 0.1236,
                                // window law 0.1017 / 0.1012 / 0.1015 / 0.1015 / 0.1024 / 0.1042 / 0.1059, config 5 x 0.25 - / - / 0.2469 / 0.2376 / 0.2439 /
                                // 0.2442 / 0.2456 ms per pass (gpurun_out/sweep2,3): narrow blocks close FEWER units (4.4 k instead of 5.2-5.4 k on config 3 --
                                // the rows of a unit share more of their transcripts) although the slices are less uniform (more padding, more stored

@@ -43,12 +43,13 @@ typedef enum {
     EMSAR_LAYOUT_AUTO = 0,   /* TILED when it applies, else CSR */
     EMSAR_LAYOUT_CSR = 1,    /* rows as given; lane-per-row walk, FP64 atomics straight to HBM/L2 */
     /* 2 was the WINDOWED layout of round 1 (4x slower than TILED, removed) */
-    EMSAR_LAYOUT_TILED = 3    /* tiles of <= 4 slices x 768 rows with a tile-local dictionary of <= 360 transcripts, kept in LDS as the 8
-                                 subset sums of every block of 3 neighbouring slots; a stored operand is 10 bits (three to a dword)
+    EMSAR_LAYOUT_TILED = 3    /* units of <= 8 slices x 768 rows with a unit-local dictionary of <= 240 transcripts, kept in LDS as the 16
+                                 subset sums of every block of 4 neighbouring slots; a stored operand is 10 bits (three to a dword)
                                  and names a block and a subset of it, so one LDS gather serves every transcript of the block that
                                  a row hits; forward index for the E-step and a per-slice transposed index for the M-step (no
-                                 atomics in the inner loops); two tiles may share a dictionary; single-tid rows folded into a
-                                 per-transcript count; rows longer than 358 tids go to a small CSR of their own */
+                                 atomics in the inner loops); single-tid rows folded into a per-transcript count; rows longer than
+                                 237 tids go to a small CSR of their own; transcripts numbered by co-occurrence inside when the
+                                 caller's numbering packs poorly (ids at this ABI stay the caller's) */
 } emsar_hip_layout;
 
 /* OR-ed into the layout argument of emsar_hip_upload_structure (TILED only): store rows with the same tid multiset

@@ -88,7 +88,8 @@ def test_layout_roundtrip_synthetic(lib, block, frag, unit, monkeypatch):
     assert info["far_entries"] > 0                          # cross-family hits fall outside their tile's window
 
 
-def test_layout_roundtrip_edge_cases(lib):
+def test_layout_roundtrip_edge_cases(lib, monkeypatch):
+    monkeypatch.setenv("EMSAR_HIP_RENUMBER", "0")               # the caller's numbering: the far-slot paths below are the point
     # empty matrix, empty rows, one row, one very long row, duplicate tids inside a row
     chk = emsar_amd.layout_selfcheck_tiled
     chk(5, np.array([0], dtype=np.uint64), np.array([], dtype=np.int32))
@@ -96,17 +97,17 @@ def test_layout_roundtrip_edge_cases(lib):
     chk(5, np.array([0, 1], dtype=np.uint64), np.array([4], dtype=np.int32))
     chk(5, np.array([0, 0, 3, 3, 4], dtype=np.uint64), np.array([2, 4, 4, 0], dtype=np.int32))
     rng = np.random.default_rng(0)
-    long_row = rng.integers(0, 3000, 700).astype(np.int32)      # 700 scattered tids: more than a tile's dictionary holds (360) -> leftover CSR
+    long_row = rng.integers(0, 3000, 700).astype(np.int32)      # 700 scattered tids: more than a tile's dictionary holds (240) -> leftover CSR
     rp = np.array([0, 700, 701], dtype=np.uint64)
     info = chk(3000, rp, np.append(long_row, 5).astype(np.int32))
     assert info["n_slices"] == 0 and info["folded_single_rows"] == 1
-    wide_row = rng.integers(0, 3000, 300).astype(np.int32)      # 300 scattered tids: one tile whose dictionary is mostly far slots
-    rp = np.array([0, 300, 301], dtype=np.uint64)
+    wide_row = rng.integers(0, 3000, 200).astype(np.int32)      # 200 scattered tids: one tile whose dictionary is mostly far slots
+    rp = np.array([0, 200, 201], dtype=np.uint64)
     info = chk(3000, rp, np.append(wide_row, 5).astype(np.int32))
     assert info["n_slices"] == 1 and info["far_entries"] > 100
-    near_row = (1000 + rng.integers(0, 120, 300)).astype(np.int32)  # 300 hits inside a window of 120 tids: neighbours share an entry
-    info = chk(3000, rp, np.append(near_row, 5).astype(np.int32))    # (an entry names a block of three tids and a subset of it)
-    assert info["n_slices"] == 1 and info["padded_entries"] % 768 == 0 and info["padded_entries"] < 768 * 300
+    near_row = (1000 + rng.integers(0, 120, 200)).astype(np.int32)  # 200 hits inside a window of 120 tids: neighbours share an entry
+    info = chk(3000, rp, np.append(near_row, 5).astype(np.int32))    # (an entry names a block of four tids and a subset of it)
+    assert info["n_slices"] == 1 and info["padded_entries"] % 768 == 0 and info["padded_entries"] < 768 * 200
 
 
 @pytest.mark.parametrize("merge", [False, True])
