@@ -460,7 +460,16 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     int unit_tiles = 2;                 // tiles that may share one dictionary (a unit: one workgroup, one dictionary load, one flush)
     if (const char *e = getenv("EMSAR_HIP_UNIT_TILES")) { int v = atoi(e); if (v >= 1 && v <= kUnitMaxTiles) unit_tiles = v; }
     if (const char *e = getenv("EMSAR_HIP_TILE_ROWS")) { int v = atoi(e); if (v >= kTileSliceRows && v <= kTileRows) tile_rows = v / kTileSliceRows * kTileSliceRows; }
-    const int64_t unit_rows = tile_rows * unit_tiles;
+    // A unit may grow beyond unit_tiles tiles' worth of rows (up to unit_tiles_max) as long as that does not fill its dictionary with far
+    // entries: rows of many neighbouring transcripts (config 5: 20 per read) pack three tiles under one dictionary with ~150 far slots,
+    // rows of gene families (config 3) would pay 2.6 x the far entries for the third tile.  Measured with a fixed 3: config 5 x 0.25
+    // 0.2121 -> 0.1896 ms, config 3 family law 0.1054 -> 0.1106, window law 0.0966 -> 0.1068 (gpurun_out/sweep4).
+    int unit_tiles_max = 3, far_soft = 160;
+    if (const char *e = getenv("EMSAR_HIP_UNIT_TILES_MAX")) { int v = atoi(e); if (v >= 1 && v <= kUnitMaxTiles) unit_tiles_max = v; }
+    if (const char *e = getenv("EMSAR_HIP_UNIT_FAR_SOFT")) { int v = atoi(e); if (v >= 0 && v <= kFarMax) far_soft = v; }
+    if (unit_tiles_max < unit_tiles) unit_tiles_max = unit_tiles;
+    const int64_t base_rows = tile_rows * unit_tiles;
+    const int64_t unit_rows = tile_rows * unit_tiles_max;
     int dense_min = kDenseMin;
     if (const char *e = getenv("EMSAR_HIP_TILE_DENSE")) { int v = atoi(e); if (v >= 1 && v <= 64) dense_min = v; }
     bool unit_sort = true;
@@ -533,7 +542,7 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             while (i1 < n_act && i1 - i0 < unit_rows) {
                 uint32_t r = perm[(size_t)i1];
                 uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-                if (i1 > i0 && ents + (int64_t)(e - b) > (int64_t)unit_tiles * kTileEntries) break;
+                if (i1 > i0 && ents + (int64_t)(e - b) > (int64_t)unit_tiles_max * kTileEntries) break;
                 size_t before = distinct.size();
                 for (uint64_t k = b; k < e; k++) {
                     int32_t t = tid_at(k);
@@ -583,9 +592,11 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
                     if (!fits(a)) continue;
                     if (!any || c - a > best_c - best_a) { best_a = a; best_c = c; any = true; }
                 }
-                if (any) break;
+                // a unit larger than the base size keeps its extra rows only if they did not flood the dictionary with far entries
+                const bool too_far = any && i1 - i0 > base_rows && (int64_t)n - (int64_t)(best_c - best_a + 1) > (int64_t)far_soft;
+                if (any && !too_far) break;
                 if (i1 - i0 <= 1) return -3;
-                const int64_t keep = i1 - i0 > kTileSliceRows ? (i1 - i0 - 1) / kTileSliceRows * kTileSliceRows : (i1 - i0) / 2;
+                const int64_t keep = too_far ? base_rows : i1 - i0 > kTileSliceRows ? (i1 - i0 - 1) / kTileSliceRows * kTileSliceRows : (i1 - i0) / 2;
                 for (int32_t t : distinct) stamp[(size_t)t] = -1;
                 distinct.clear();
                 i1 = i0 + std::max<int64_t>(keep, 1);
