@@ -22,7 +22,10 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <numeric>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 namespace emsar {
@@ -62,61 +65,103 @@ inline void cooccurrence_order(int64_t n_rows, int32_t n_tx, const uint64_t *row
         if (len >= 2 && len <= (uint64_t)max_row_len) multi_ids += (int64_t)len;
     }
     if (multi_ids == 0) return;
-    const int64_t stride = std::max<int64_t>(1, (multi_ids + kRenumberMaxPairs - 1) / kRenumberMaxPairs);
-    struct Slot { uint64_t key; uint32_t cnt; };
-    uint64_t cap = 1 << 16;
-    std::vector<Slot> table((size_t)cap, Slot{~0ull, 0});
-    uint64_t used = 0;
-    auto hash = [](uint64_t k) { k ^= k >> 31; k *= 0x9E3779B97F4A7C15ull; k ^= k >> 29; k *= 0xBF58476D1CE4E5B9ull; k ^= k >> 32; return k; };
-    auto grow = [&]() {
-        std::vector<Slot> old;
-        old.swap(table);
-        cap <<= 1;
-        table.assign((size_t)cap, Slot{~0ull, 0});
-        for (const Slot &s : old) {
-            if (s.key == ~0ull) continue;
-            uint64_t h = hash(s.key) & (cap - 1);
-            while (table[(size_t)h].key != ~0ull) h = (h + 1) & (cap - 1);
-            table[(size_t)h] = s;
+    int64_t max_pairs = kRenumberMaxPairs;
+    if (const char *ev = getenv("EMSAR_HIP_RENUMBER_PAIRS")) { const long long v = atoll(ev); if (v >= 1024) max_pairs = (int64_t)v; }
+    const int64_t stride = std::max<int64_t>(1, (multi_ids + max_pairs - 1) / max_pairs);
+    // the rows of the sample (one cheap sequential scan), then the pair counts on up to 16 host threads: every thread turns its share of
+    // the sampled rows into pair keys (phase 1), then owns the keys of one hash class and counts them in a table of its own (phase 2: the
+    // random-access inserts are what costs -- 2 s on one thread for 12 M pairs).  The set of (pair, count) is the same for any thread
+    // count, and the edges are sorted by a total order below, so the numbering does not depend on the number of threads.
+    std::vector<int64_t> sampled;
+    {
+        int64_t seen_multi = 0;
+        for (int64_t r = 0; r < n_rows; r++) {
+            const uint64_t len = row_ptr[r + 1] - row_ptr[r];
+            if (len < 2 || len > (uint64_t)max_row_len) continue;
+            if (seen_multi++ % stride) continue;
+            sampled.push_back(r);
         }
-    };
-    auto add_pair = [&](int32_t a, int32_t b) {
-        if (a == b) return;
-        if (a > b) std::swap(a, b);
-        const uint64_t key = (uint64_t)(uint32_t)a << 32 | (uint32_t)b;
-        uint64_t h = hash(key) & (cap - 1);
-        for (;;) {
-            Slot &s = table[(size_t)h];
-            if (s.key == key) { s.cnt++; return; }
-            if (s.key == ~0ull) { s.key = key; s.cnt = 1; if (++used * 2 > cap) grow(); return; }
-            h = (h + 1) & (cap - 1);
-        }
-    };
-    std::vector<int32_t> tmp;
-    std::vector<int64_t> sampled;             // the rows of the sample (for the comparison of step 5)
-    int64_t seen_multi = 0;
-    for (int64_t r = 0; r < n_rows; r++) {
-        const uint64_t b = row_ptr[r], e = row_ptr[r + 1], len = e - b;
-        if (len < 2 || len > (uint64_t)max_row_len) continue;
-        if (seen_multi++ % stride) continue;
-        sampled.push_back(r);
-        tmp.assign(col_idx + b, col_idx + e);
-        std::sort(tmp.begin(), tmp.end());
-        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-        const size_t n = tmp.size();
-        for (size_t i = 0; i + 1 < n; i++) add_pair(tmp[i], tmp[i + 1]);
-        if (n > 2) add_pair(tmp[0], tmp[n - 1]);
-        st.pairs_sampled += (int64_t)(n > 2 ? n : n - 1);
     }
     st.rows_sampled = (int64_t)sampled.size();
-    st.pairs_distinct = (int64_t)used;
-    // ---- 2. clusters: Kruskal with a size cap over the pairs seen at least `min_cnt` times ----
+    int nt = 1;
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        nt = (int)(hw ? std::min(hw, 16u) : 1u);
+        if (sampled.size() < ((size_t)1 << 15)) nt = 1;
+        if (const char *ev = getenv("EMSAR_HOST_THREADS")) { const int v = atoi(ev); if (v >= 1) nt = std::min(v, 64); }
+    }
+    auto hash = [](uint64_t k) { k ^= k >> 31; k *= 0x9E3779B97F4A7C15ull; k ^= k >> 29; k *= 0xBF58476D1CE4E5B9ull; k ^= k >> 32; return k; };
+    auto on_threads = [&](auto fn) {
+        std::vector<std::thread> pool;
+        bool failed = false;
+        for (int t = 1; t < nt; t++) {
+            try { pool.emplace_back([&, t] { try { fn(t); } catch (const std::bad_alloc &) { failed = true; } }); }
+            catch (const std::system_error &) { try { fn(t); } catch (const std::bad_alloc &) { failed = true; } }
+        }
+        try { fn(0); } catch (const std::bad_alloc &) { failed = true; }
+        for (auto &th : pool) th.join();
+        if (failed) throw std::bad_alloc();
+    };
+    std::vector<std::vector<uint64_t>> keys((size_t)nt);
+    on_threads([&](int t) {
+        std::vector<int32_t> tmp;
+        std::vector<uint64_t> &K = keys[(size_t)t];
+        auto put = [&](int32_t a, int32_t b) { if (a != b) K.push_back(a < b ? (uint64_t)(uint32_t)a << 32 | (uint32_t)b : (uint64_t)(uint32_t)b << 32 | (uint32_t)a); };
+        const size_t lo = sampled.size() * (size_t)t / (size_t)nt, hi = sampled.size() * (size_t)(t + 1) / (size_t)nt;
+        for (size_t q = lo; q < hi; q++) {
+            const int64_t r = sampled[q];
+            tmp.assign(col_idx + row_ptr[r], col_idx + row_ptr[r + 1]);
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            const size_t n = tmp.size();
+            for (size_t i = 0; i + 1 < n; i++) put(tmp[i], tmp[i + 1]);
+            if (n > 2) put(tmp[0], tmp[n - 1]);
+        }
+    });
+    for (const auto &K : keys) st.pairs_sampled += (int64_t)K.size();
     const uint32_t min_cnt = st.pairs_sampled >= (1 << 20) ? 2u : 1u;
     struct Edge { int32_t a, b; uint32_t w; };
+    std::vector<std::vector<Edge>> part((size_t)nt);
+    std::vector<int64_t> part_used((size_t)nt, 0);
+    on_threads([&](int t) {
+        struct Slot { uint64_t key; uint32_t cnt; };
+        uint64_t cap = 1 << 14, used = 0;
+        std::vector<Slot> table((size_t)cap, Slot{~0ull, 0});
+        for (const auto &K : keys)
+            for (const uint64_t key : K) {
+                const uint64_t hh = hash(key);
+                if ((int)((hh >> 40) % (uint64_t)nt) != t) continue;
+                uint64_t h = hh & (cap - 1);
+                for (;;) {
+                    Slot &sl = table[(size_t)h];
+                    if (sl.key == key) { sl.cnt++; break; }
+                    if (sl.key == ~0ull) {
+                        sl.key = key; sl.cnt = 1;
+                        if (++used * 2 > cap) {                    // grow
+                            std::vector<Slot> old;
+                            old.swap(table);
+                            cap <<= 1;
+                            table.assign((size_t)cap, Slot{~0ull, 0});
+                            for (const Slot &o : old) {
+                                if (o.key == ~0ull) continue;
+                                uint64_t g = hash(o.key) & (cap - 1);
+                                while (table[(size_t)g].key != ~0ull) g = (g + 1) & (cap - 1);
+                                table[(size_t)g] = o;
+                            }
+                        }
+                        break;
+                    }
+                    h = (h + 1) & (cap - 1);
+                }
+            }
+        part_used[(size_t)t] = (int64_t)used;
+        for (const Slot &sl : table)
+            if (sl.key != ~0ull && sl.cnt >= min_cnt) part[(size_t)t].push_back(Edge{(int32_t)(sl.key >> 32), (int32_t)(sl.key & 0xFFFFFFFFu), sl.cnt});
+    });
+    std::vector<std::vector<uint64_t>>().swap(keys);
     std::vector<Edge> edges;
-    for (const Slot &s : table)
-        if (s.key != ~0ull && s.cnt >= min_cnt) edges.push_back(Edge{(int32_t)(s.key >> 32), (int32_t)(s.key & 0xFFFFFFFFu), s.cnt});
-    std::vector<Slot>().swap(table);
+    for (int t = 0; t < nt; t++) { st.pairs_distinct += part_used[(size_t)t]; edges.insert(edges.end(), part[(size_t)t].begin(), part[(size_t)t].end()); }
+    std::vector<std::vector<Edge>>().swap(part);
     st.pairs_kept = (int64_t)edges.size();
     if (edges.empty()) return;
     std::sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) {      // heaviest first; ties by ids: the order is a function of the data
@@ -193,17 +238,24 @@ inline void cooccurrence_order(int64_t n_rows, int32_t n_tx, const uint64_t *row
     }
     // ---- 5. keep it only if the sampled rows need fewer block entries ----
     int64_t e0 = 0, e1 = 0, ids = 0;
-    std::vector<int32_t> tmp2;
-    for (int64_t r : sampled) {
-        const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-        tmp.assign(col_idx + b, col_idx + e);
-        std::sort(tmp.begin(), tmp.end());
-        e0 += row_entries(tmp.data(), (int)tmp.size(), blk);
-        tmp2.resize(tmp.size());
-        for (size_t i = 0; i < tmp.size(); i++) tmp2[i] = cand[(size_t)tmp[i]];
-        std::sort(tmp2.begin(), tmp2.end());
-        e1 += row_entries(tmp2.data(), (int)tmp2.size(), blk);
-        ids += (int64_t)tmp.size();
+    {
+        std::vector<int64_t> pe0((size_t)nt, 0), pe1((size_t)nt, 0), pid((size_t)nt, 0);
+        on_threads([&](int t) {
+            std::vector<int32_t> tmp, tmp2;
+            const size_t lo = sampled.size() * (size_t)t / (size_t)nt, hi = sampled.size() * (size_t)(t + 1) / (size_t)nt;
+            for (size_t q = lo; q < hi; q++) {
+                const int64_t r = sampled[q];
+                tmp.assign(col_idx + row_ptr[r], col_idx + row_ptr[r + 1]);
+                std::sort(tmp.begin(), tmp.end());
+                pe0[(size_t)t] += row_entries(tmp.data(), (int)tmp.size(), blk);
+                tmp2.resize(tmp.size());
+                for (size_t i = 0; i < tmp.size(); i++) tmp2[i] = cand[(size_t)tmp[i]];
+                std::sort(tmp2.begin(), tmp2.end());
+                pe1[(size_t)t] += row_entries(tmp2.data(), (int)tmp2.size(), blk);
+                pid[(size_t)t] += (int64_t)tmp.size();
+            }
+        });
+        for (int t = 0; t < nt; t++) { e0 += pe0[(size_t)t]; e1 += pe1[(size_t)t]; ids += pid[(size_t)t]; }
     }
     st.entries_before = e0; st.entries_after = e1; st.ids_sampled = ids;
     bool force = false, never = false;
