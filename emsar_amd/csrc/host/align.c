@@ -149,7 +149,10 @@ static int bam_next(bamreader *b, samrec *r) {
                 size_t n = 0;
                 while (off + n < (size_t)bs && p[off + n]) n++;
                 if (off + n >= (size_t)bs) return -1;
-                if (a[0] == 'M' && a[1] == 'D' && ty == 'Z') snprintf(r->md, sizeof r->md, "%s", (const char *)(p + off));
+                if (a[0] == 'M' && a[1] == 'D' && ty == 'Z') {        /* (snprintf("%s") here was a fifth of the per-record cost) */
+                    const size_t k = n < sizeof r->md - 1 ? n : sizeof r->md - 1;
+                    memcpy(r->md, p + off, k); r->md[k] = 0;
+                }
                 len = n + 1; break;
             }
             case 'B': {

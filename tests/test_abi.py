@@ -168,3 +168,15 @@ def test_renumbering_recovers_shuffled_families(lib, monkeypatch):
     assert per["shuffled_off"][0] < 1.05 and per["shuffled_off"][1] == 0
     assert per["shuffled"][1] == 1 and per["shuffled"][0] > 0.95 * per["family"][0]
     assert per["shuffled"][2] < 2 * per["family"][2] + 1000          # and the cross-family hits are the only far ones again
+
+
+def test_numbering_does_not_depend_on_the_thread_count(lib, monkeypatch):
+    # the pair counts of csrc/renumber.hpp are made by several host threads (keys split by hash class): same clusters, same layout
+    m = synth.make_matrix(n_tx=8000, n_reads=300000, law="human", xfam=0.02, seed=23, structure="family_shuffled")
+    monkeypatch.setenv("EMSAR_HIP_RENUMBER", "2")
+    seen = set()
+    for threads in ("1", "2", "5", "16"):
+        monkeypatch.setenv("EMSAR_HOST_THREADS", threads)
+        i = emsar_amd.layout_selfcheck_tiled(m["n_tx"], m["row_ptr"], m["col_idx"])
+        seen.add((i["tiled_entries"], i["far_entries"], i["n_units"], i["padded_entries"], i["stored_bytes_per_pass"]))
+    assert len(seen) == 1, seen
