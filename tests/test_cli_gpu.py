@@ -298,3 +298,18 @@ def test_config4_shape_at_one_hundredth(tmp_path):
         bad = (np.abs(got - a[0]) > 1e-5 * np.abs(a[0]) + 1.5e-6) & ~mask
         assert bad.sum() <= 2, (int(bad.sum()), np.nonzero(bad)[0][:5], got[bad][:5], a[0][bad][:5])
         assert open(os.path.join(work, "w4", "o.0.fraglength_effect")).read() == open(os.path.join(work, "ref0", "o.0.fraglength_effect")).read()
+
+
+@pytest.mark.parametrize("case", ["syn2k_se", "vicugna_pe", "toy5_pe_bam"])
+def test_library_numbering_does_not_show_in_the_files(case, tmp_path):
+    """The TILED layout may number the transcripts by co-occurrence (csrc/renumber.hpp); ids at the ABI stay the caller's, so the files
+    emsar-hip writes are the same bytes with the numbering forced on, off, or left to the data."""
+    fx = get_fixture(case)
+    out = {}
+    for mode in ("0", "2", "1"):
+        d = tmp_path / ("m" + mode)
+        cmd = [CLI, "-q", "-g"] + fx.meta["opts"] + ["-I", os.path.join(fx.dir, "index.rsh"), str(d), "out", _aln(fx)]
+        subprocess.run(cmd, check=True, timeout=300, env=dict(os.environ, EMSAR_HIP_RENUMBER=mode))
+        out[mode] = {ext: open(d / ("out.0." + ext), "rb").read() for ext in ("fpkm", "segments", "fraglength_effect")}
+    assert out["0"] == out["2"] == out["1"]
+    _check_fpkm_file(fx, str(tmp_path / "m2" / "out.0.fpkm"))

@@ -48,16 +48,21 @@ def test_fixtures_resident_vs_streaming_vs_reference(dev, golden, accel):
     assert st_r2.set_passes_sum == st_r.set_passes_sum
 
 
-@pytest.mark.parametrize("layout", [LAYOUT_CSR, LAYOUT_TILED])
+@pytest.mark.parametrize("layout,renumber", [(LAYOUT_CSR, "1"), (LAYOUT_TILED, "0"), (LAYOUT_TILED, "2")])
 @pytest.mark.parametrize("cluster", ["0", "1"])
-def test_every_class_and_a_streamed_set(dev, layout, cluster, monkeypatch):
+def test_every_class_and_a_streamed_set(dev, layout, renumber, cluster, monkeypatch):
     monkeypatch.setenv("EMSAR_HIP_CLUSTER", cluster)
-    n_tx, rp, ci, w = family_matrix([2, 3, 5, 8, 40, 200, 900, 2500, 6000] + [4] * 300, rows_per_tid=2, seed=5)
+    monkeypatch.setenv("EMSAR_HIP_RENUMBER", renumber)     # 2: the library's own transcript numbering forced on -- the set records (found on
+    n_tx, rp, ci, w = family_matrix([2, 3, 5, 8, 40, 200, 900, 2500, 6000] + [4] * 300, rows_per_tid=2, seed=5)       # the caller's CSR) are mapped
     rng = np.random.default_rng(9)
+    shuffle = rng.permutation(n_tx).astype(np.int32)       # ... and the caller's ids carry no locality
+    ci = shuffle[ci]
     E = rng.uniform(0.5, 2.0, size=len(w))
     E[rng.random(len(w)) < 0.05] = 0.0                    # rows outside the likelihood
     dev.upload_structure(n_tx, rp, ci, layout)
     dev.upload_sample(w, E, None)
+    if layout == LAYOUT_TILED:
+        assert dev.info()["renumbered"] == int(renumber == "2")
     th_r, st_r = dev.solve(max_iter=400000, accel=1, tol=1e-10, set_mode=0)
     th_s, st_s = dev.solve(max_iter=400000, accel=1, tol=1e-10, set_mode=1)
     assert st_r.converged == 1 and st_s.converged == 1
