@@ -45,10 +45,11 @@ lst = os.path.join(work, "list.txt")
 open(lst, "w").write("\n".join(bams) + "\n")
 rsh = os.path.join(work, "index.rsh")
 print("host: %d cores visible, EMSAR_HOST_THREADS default min(cores, 16) = %d" % (cores, threads), flush=True)
+extra = os.environ.get("CFG4_EXTRA", "").split()          # e.g. CFG4_EXTRA=--device-collapse
 for label, dev in (("1 worker", "0"), ("%d workers on one GPU" % workers, ",".join(["0"] * workers))):
     out = os.path.join(work, "out_" + label.split()[0])
     t0 = time.time()
-    subprocess.run([HIP, "-q", "-M", "-B", "--devices", dev, "--stats-json", os.path.join(work, "st.json"), "-I", rsh, out, "o", lst], check=True,
+    subprocess.run([HIP, "-q", "-M", "-B"] + extra + ["--devices", dev, "--stats-json", os.path.join(work, "st.json"), "-I", rsh, out, "o", lst], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     wall = time.time() - t0
     st = json.load(open(os.path.join(work, "st.json")))
