@@ -848,6 +848,24 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             else { out.tiles[i].follows = 0; units.push_back(Unit{(uint32_t)i, 1u, work(out.tiles[i])}); }
         }
         std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.w > b.w; });
+        // The tail: with ~3.4 k units for 1024 workgroup slots the last workgroups run on a half-empty chip (timeline of config 3: 14 of
+        // 114 us below 75 % occupancy).  The lightest units are therefore cut into their tiles -- every tile carries the dictionary
+        // descriptor, so a tile that stops following is a unit of its own -- and the small pieces fill the tail.  Measured (EMSAR_HIP_TAIL_SPLIT =
+        // share of the units cut, config 3): 0 / 10 / 20 / 35 / 50 % -> family law 0.1071 / 0.1055 / 0.1075 / 0.1077 / 0.1108 ms, window law
+        // 0.0967 / 0.0976 / 0.0986 / 0.1000: what the tail gains the extra per-unit overhead takes back.  Off.
+        int tail_pct = 0;
+        if (const char *e = getenv("EMSAR_HIP_TAIL_SPLIT")) { int v = atoi(e); if (v >= 0 && v <= 100) tail_pct = v; }
+        if (tail_pct > 0 && units.size() > 2048) {
+            const size_t keep = units.size() - units.size() * (size_t)tail_pct / 100;
+            std::vector<Unit> cut(units.begin(), units.begin() + (std::ptrdiff_t)keep);
+            for (size_t q = keep; q < units.size(); q++)
+                for (uint32_t j = 0; j < units[q].n; j++) {
+                    out.tiles[units[q].first + j].follows = 0;
+                    cut.push_back(Unit{units[q].first + j, 1u, work(out.tiles[units[q].first + j])});
+                }
+            std::stable_sort(cut.begin() + (std::ptrdiff_t)keep, cut.end(), [](const Unit &a, const Unit &b) { return a.w > b.w; });
+            units.swap(cut);
+        }
         std::vector<Tile> sorted_tiles;
         sorted_tiles.reserve(out.tiles.size());
         out.unit_first.clear();

@@ -8,7 +8,7 @@ from emsar_amd import EmsarHip, synth
 s = synth.make_config("cfg3", 1.0, "family")
 dev = EmsarHip(0)
 def run(env):
-    for k in ("EMSAR_HIP_UNIT_FAR_SOFT", "EMSAR_HIP_UNIT_TILES_MAX", "EMSAR_HIP_TILE_BLOCK", "EMSAR_HIP_UNIT_TILES", "EMSAR_HIP_TILE_ROWS", "EMSAR_HIP_RENUMBER", "EMSAR_HIP_SHORT_ECNT", "EMSAR_HIP_SHORT_BLOCK"):
+    for k in ("EMSAR_HIP_TAIL_SPLIT", "EMSAR_HIP_UNIT_FAR_SOFT", "EMSAR_HIP_UNIT_TILES_MAX", "EMSAR_HIP_TILE_BLOCK", "EMSAR_HIP_UNIT_TILES", "EMSAR_HIP_TILE_ROWS", "EMSAR_HIP_RENUMBER", "EMSAR_HIP_SHORT_ECNT", "EMSAR_HIP_SHORT_BLOCK"):
         os.environ.pop(k, None)
     os.environ.update(env)
     os.environ.setdefault("EMSAR_HIP_RENUMBER", "0")
@@ -19,16 +19,11 @@ def run(env):
     ms = min(dev.run_passes(200) / 200 for _ in range(3))
     print(env, "ms/pass %.4f" % ms, "units", i["n_units"], "tiles", i["n_chunks"], "padded", i["padded_entries"], "entries", i["tiled_entries"], "far", i["far_entries"],
           "stored MB %.1f" % (i["stored_bytes_per_pass"] / 1e6), flush=True)
-for f in ("0", "96", "160", "256", "400"):
-    run({"EMSAR_HIP_UNIT_FAR_SOFT": f})
+for f in ("0", "10", "20", "35", "50"):
+    run({"EMSAR_HIP_TAIL_SPLIT": f})
 s = synth.make_config("cfg3", 1.0, "window")
 print("window law", flush=True)
-for f in ("0", "96", "160", "256", "400"):
-    run({"EMSAR_HIP_UNIT_FAR_SOFT": f})
-s = synth.make_config("cfg5", 0.25, "window")
-print("cfg5 x 0.25", flush=True)
-for f in ("0", "96", "160", "256"):
-    run({"EMSAR_HIP_UNIT_FAR_SOFT": f})
-run({"EMSAR_HIP_UNIT_FAR_SOFT": "160", "EMSAR_HIP_UNIT_TILES_MAX": "4"})
+for f in ("0", "10", "20", "35"):
+    run({"EMSAR_HIP_TAIL_SPLIT": f})
 PY
 cat $O/sweep.txt

@@ -5,7 +5,7 @@ import numpy as np
 from emsar_amd import EmsarHip, synth
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-s = synth.make_config(cfg, scale)
+s = synth.make_config(cfg, scale, sys.argv[3] if len(sys.argv) > 3 else "family")
 dev = EmsarHip(0)
 dev.upload_structure(s["n_tx"], s["row_ptr"], s["col_idx"], 3)
 dev.upload_sample(None, None, s["den"])
