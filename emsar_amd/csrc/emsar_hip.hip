@@ -492,6 +492,11 @@ int solve_resident_sets(emsar_hip_ctx *ctx, const SetSolveParams &P, const SetSo
             first = last;
         }
         HIPCHK(hipEventRecord(ctx->ev_c1, ctx->side[2]));
+        // The workgroups of a cluster wait for each other inside the launch, so all of them must get a CU: nothing else may hold CUs while
+        // the cluster batches run (k_solve_sets<512> asks for most of a CU's LDS too).  The size classes below start after the clusters.
+        HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_c1, 0));
+        HIPCHK(hipStreamWaitEvent(ctx->side[1], ctx->ev_c1, 0));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_c1, 0));
     }
     LAUNCH_S(2, 512, ctx->side[1])      // the big ones first: they are the fewest and the longest per pass
     LAUNCH_S(1, 256, ctx->side[0])
