@@ -68,7 +68,6 @@ struct emsar_hip_ctx {
     Tile *d_utiles = nullptr; int unit_stride = 1;   // emsar::UnitTables
     uint32_t *d_units = nullptr; int64_t n_units = 0;     // units of one or two tiles that share a dictionary (k_pass_tiled_unit)
     uint32_t *d_fwd = nullptr, *d_bwd = nullptr;
-    uint32_t *d_coo = nullptr;
     int32_t *d_far = nullptr;
     uint64_t *d_left_ptr = nullptr; int32_t *d_left_col = nullptr; int32_t *d_left_wgt = nullptr; double *d_left_val = nullptr;
     int64_t n_left = 0, n_tiles = 0, n_slots = 0;
@@ -185,9 +184,9 @@ void free_structure(emsar_hip_ctx *ctx) {
     dfree(ctx->d_wgt); dfree(ctx->d_rowval); ctx->d_wgt = nullptr; ctx->d_rowval = nullptr;
     dfree(ctx->d_units); ctx->d_units = nullptr; ctx->n_units = 0;
     dfree(ctx->d_utiles); ctx->d_utiles = nullptr;
-    dfree(ctx->d_tiles); dfree(ctx->d_fwd); dfree(ctx->d_bwd); dfree(ctx->d_coo); dfree(ctx->d_far);
+    dfree(ctx->d_tiles); dfree(ctx->d_fwd); dfree(ctx->d_bwd); dfree(ctx->d_far);
     dfree(ctx->d_left_ptr); dfree(ctx->d_left_col); dfree(ctx->d_left_wgt); dfree(ctx->d_left_val); dfree(ctx->d_u);
-    ctx->d_tiles = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_coo = nullptr; ctx->d_far = nullptr;
+    ctx->d_tiles = nullptr; ctx->d_fwd = ctx->d_bwd = nullptr; ctx->d_far = nullptr;
     ctx->d_left_ptr = nullptr; ctx->d_left_col = nullptr; ctx->d_left_wgt = nullptr; ctx->d_left_val = nullptr; ctx->d_u = nullptr;
     ctx->TL = emsar::TiledLayout(); ctx->n_left = ctx->n_tiles = ctx->n_slots = 0;
     dfree(ctx->d_den); dfree(ctx->d_acc); ctx->d_den = nullptr; ctx->d_acc = nullptr;
@@ -208,10 +207,10 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
             dim3 grid((unsigned)ctx->n_tiles), block(kTiledThreads);
 #define LAUNCH_T(WT, MD)                                                                                          \
     hipLaunchKernelGGL((k_pass_tiled<WT, MD>), grid, block, lds, ctx->stream, ctx->d_tiles, ctx->d_fwd, ctx->d_bwd,   \
-                       ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out, fx_of(ctx, mode))
+                       ctx->d_far, ctx->d_wgt, ctx->d_rowval, theta, acc, ll_out, fx_of(ctx, mode))
 #define LAUNCH_PN(WT, MD, NN)                                                                                     \
     hipLaunchKernelGGL((k_pass_tiled_multi<WT, MD, NN>), dim3((unsigned)((ctx->n_tiles + NN - 1) / NN)), block, lds, ctx->stream, ctx->d_tiles,  \
-                       (int)ctx->n_tiles, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, theta, acc, ll_out, fx_of(ctx, mode))
+                       (int)ctx->n_tiles, ctx->d_fwd, ctx->d_bwd, ctx->d_far, ctx->d_wgt, theta, acc, ll_out, fx_of(ctx, mode))
 #define LAUNCH_P(WT, MD) LAUNCH_PN(WT, MD, 2)
             if (mode == MODE_SCATTER) LAUNCH_T(false, MODE_SCATTER);
             else if (!ctx->weighted && (ctx->tiled_multi >= 2 || (ctx->tiled_multi == 1 && ctx->n_tiles > kPairMinTiles))) {
@@ -224,7 +223,7 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
                 // a pair takes twice as long as a tile (40 k reads: 47 -> 26 us per pass with one tile per workgroup)
                 if (ctx->tiled_multi == 1 || ctx->tiled_multi == 5) {         // units: one dictionary for up to two tiles
 #define LAUNCH_U(WT, MD) hipLaunchKernelGGL((k_pass_tiled_unit<WT, MD>), dim3((unsigned)ctx->n_units), block, lds, ctx->stream, ctx->d_utiles, ctx->unit_stride, \
-                                           ctx->d_far, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_wgt, theta, acc, ll_out, fx_of(ctx, mode))
+                                           ctx->d_far, ctx->d_fwd, ctx->d_bwd, ctx->d_wgt, theta, acc, ll_out, fx_of(ctx, mode))
                     if (mode == MODE_EM_LL) LAUNCH_U(false, MODE_EM_LL); else LAUNCH_U(false, MODE_EM);
 #undef LAUNCH_U
                 }
@@ -241,7 +240,7 @@ int launch_pass(emsar_hip_ctx *ctx, int mode, const double *theta, double *acc, 
                 // kernel's unrolled logs (solve 0.161 against 0.150 ms per pass), so by default (1) only the plain EM pass of a SQUAREM
                 // cycle runs here and the two likelihood passes stay with k_pass_tiled; 2 = both, 0 = neither (EMSAR_HIP_WEIGHTED_UNIT)
                 hipLaunchKernelGGL((mode == MODE_EM_LL ? k_pass_tiled_unit<true, MODE_EM_LL> : k_pass_tiled_unit<true, MODE_EM>), dim3((unsigned)ctx->n_units), block, lds,
-                                   ctx->stream, ctx->d_utiles, ctx->unit_stride, ctx->d_far, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_wgt, theta, acc, ll_out,
+                                   ctx->stream, ctx->d_utiles, ctx->unit_stride, ctx->d_far, ctx->d_fwd, ctx->d_bwd, ctx->d_wgt, theta, acc, ll_out,
                                    fx_of(ctx, mode), (unsigned long long *)nullptr);
             }
             else if (ctx->weighted) { if (mode == MODE_EM_LL) LAUNCH_T(true, MODE_EM_LL); else LAUNCH_T(true, MODE_EM); }
@@ -650,16 +649,15 @@ int emsar_hip_upload_structure(emsar_hip_ctx *ctx, int64_t n_rows, int32_t n_tx,
             }
             HIPCHK(up((void **)&ctx->d_fwd, L.fwd.data(), L.fwd.size() * 4));
             HIPCHK(up((void **)&ctx->d_bwd, L.bwd.data(), L.bwd.size() * 4));
-            HIPCHK(up((void **)&ctx->d_coo, L.coo.data(), L.coo.size() * 4));
             HIPCHK(up((void **)&ctx->d_far, L.far_tid.data(), L.far_tid.size() * 4));
             HIPCHK(up((void **)&ctx->d_left_ptr, L.left_ptr.data(), L.left_ptr.size() * 8));
             HIPCHK(up((void **)&ctx->d_left_col, L.left_col.data(), L.left_col.size() * 4));
             HIPCHK(hipMalloc(&ctx->d_u, T * 8));
             HIPCHK(hipMemset(ctx->d_u, 0, T * 8));
-            ctx->bytes_stored = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 + (int64_t)L.far_tid.size() * 4 +
+            ctx->bytes_stored = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.far_tid.size() * 4 +
                                 (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4 + (int64_t)L.left_ptr.size() * 8;
             ctx->tl_fwd_slots = L.padded_slots; ctx->tl_n_fslices = L.n_fslices;
-            emsar::u32_vec().swap(L.fwd); emsar::u32_vec().swap(L.bwd); std::vector<uint32_t>().swap(L.coo);
+            emsar::u32_vec().swap(L.fwd); emsar::u32_vec().swap(L.bwd);
             std::vector<int32_t>().swap(L.left_col);
             const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
 #define SETLDS_T(WT, MD) HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<WT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
@@ -1132,7 +1130,7 @@ int emsar_hip_debug_tiled_stamps(emsar_hip_ctx *ctx, double *out) {
     const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
     HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled<false, MODE_EM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_pass_tiled<false, MODE_EM, true>), dim3((unsigned)ctx->n_tiles), dim3(kTiledThreads), lds, ctx->stream, ctx->d_tiles,
-                       ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_far, ctx->d_wgt, ctx->d_rowval, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].s[0].v, Fx{0.0, 0.0}, d);
+                       ctx->d_fwd, ctx->d_bwd, ctx->d_far, ctx->d_wgt, ctx->d_rowval, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].s[0].v, Fx{0.0, 0.0}, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
     std::vector<unsigned long long> h(nw * 8);
@@ -1160,7 +1158,7 @@ int emsar_hip_debug_unit_stamps(emsar_hip_ctx *ctx, double *out, unsigned long l
     const size_t lds = (size_t)kTiledLdsDoubles * sizeof(double);
     HIPCHK(hipFuncSetAttribute((const void *)k_pass_tiled_unit<false, MODE_EM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_pass_tiled_unit<false, MODE_EM, true>), dim3((unsigned)ctx->n_units), dim3(kTiledThreads), lds, ctx->stream, ctx->d_utiles, ctx->unit_stride,
-                       ctx->d_far, ctx->d_fwd, ctx->d_bwd, ctx->d_coo, ctx->d_wgt, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].s[0].v, Fx{0.0, 0.0}, d);
+                       ctx->d_far, ctx->d_fwd, ctx->d_bwd, ctx->d_wgt, ctx->d_th[0], ctx->d_acc, &ctx->d_scal->ll[3].s[0].v, Fx{0.0, 0.0}, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_acc, 0, (size_t)ctx->n_tx * 8, ctx->stream));
     std::vector<unsigned long long> h(nw * 8 + (size_t)ctx->n_units * 4);
@@ -1192,7 +1190,7 @@ int emsar_hip_layout_selfcheck_tiled(int64_t n_rows, int32_t n_tx, const uint64_
             info_out->n_chunks = (int64_t)L.tiles.size();
             info_out->n_slices = L.n_fslices;
             info_out->padded_entries = L.padded_slots; info_out->far_entries = L.far_entries; info_out->window = emsar::kTileDict;
-            info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 + (int64_t)L.coo.size() * 4 +
+            info_out->stored_bytes_per_pass = (int64_t)L.fwd.size() * 4 + (int64_t)L.bwd.size() * 4 +
                                               (int64_t)L.far_tid.size() * 4 + (int64_t)L.tiles.size() * 64 + (int64_t)L.left_col.size() * 4;
             info_out->bytes_per_pass = (int64_t)L.single_row.size();   /* diagnostic: number of folded single-tid rows */
             info_out->tiled_entries = L.tiled_entries; info_out->tiled_ids = L.tiled_ids; info_out->renumbered = L.renum.applied ? 1 : 0;

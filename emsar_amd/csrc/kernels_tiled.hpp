@@ -118,6 +118,43 @@ __device__ __forceinline__ void tile_acc_add(double *acc_w, unsigned off, double
     if (fx != 0.0) lds_add_i64(p, __double2ll_rn(part * *(p - kTiledDictPad) * fx));
     else lds_add_f64(p, part);
 }
+// Every vector-memory request of this wave has landed.  Placed where a wave-uniform branch may have skipped the code that consumed a load
+// (a wave without dictionary work skips block_dict_store): hipcc's s_waitcnt pass then carries the load as PENDING into the tile loop and
+// puts s_waitcnt vmcnt(0) in front of the first instruction that reuses its register -- in the middle of the E-step, where it waits for
+// the index loads issued to run ahead.
+__device__ __forceinline__ void vm_loads_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), expcnt and lgkmcnt untouched
+
+// A tile descriptor as the kernels hold it: every field a register of its own, decoded from SIXTEEN DWORDS read at a wave-uniform address
+// (scalar loads).  Reading emsar::Tile's 8- and 16-bit fields directly makes hipcc fetch each of them with a VECTOR load (global_load_ushort /
+// _ubyte + s_waitcnt vmcnt(0) + v_readfirstlane: there is no scalar sub-dword load) -- a memory round trip in the middle of the tile loop that
+// also waits for every index load in flight.
+struct DTile {
+    uint64_t fwd_off, bwd_off;
+    uint32_t row_base, far_off;
+    int32_t lo;
+    uint32_t near_n, far_n, n_slices, follows, wave_of;
+    uint32_t k[4], m[4];
+};
+struct TileWords { uint32_t w[16]; };
+static_assert(sizeof(TileWords) == sizeof(Tile), "tile_load reads a Tile as 16 dwords");
+static_assert(offsetof(Tile, row_base) == 16 && offsetof(Tile, lo) == 28 && offsetof(Tile, near_n) == 32 && offsetof(Tile, n_slices) == 36 && offsetof(Tile, follows) == 38 &&
+              offsetof(Tile, wave_of) == 39 && offsetof(Tile, k) == 40 && offsetof(Tile, m) == 48 && offsetof(Tile, coo_n) == 56, "tile_load's field positions");
+__device__ __forceinline__ DTile tile_load(const Tile *p /* wave-uniform */) {
+    const TileWords r = *reinterpret_cast<const TileWords *>(p);
+    DTile T;
+    T.fwd_off = (uint64_t)r.w[0] | (uint64_t)r.w[1] << 32;
+    T.bwd_off = (uint64_t)r.w[2] | (uint64_t)r.w[3] << 32;
+    T.row_base = r.w[4]; T.far_off = r.w[5]; T.lo = (int32_t)r.w[7];
+    T.near_n = r.w[8] & 0xFFFFu; T.far_n = r.w[8] >> 16;
+    T.n_slices = r.w[9] & 0xFFFFu; T.follows = (r.w[9] >> 16) & 0xFFu; T.wave_of = r.w[9] >> 24;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        T.k[s] = (r.w[10 + s / 2] >> (16 * (s & 1))) & 0xFFFFu;
+        T.m[s] = (r.w[12 + s / 2] >> (16 * (s & 1))) & 0xFFFFu;
+    }
+    return T;
+}
+
 // ---- the dictionary of a tile (layout_tiled.hpp): near blocks of three transcripts with eight subset sums each, then one entry
 // per far transcript ----
 // Thread b < nb (the tile's near blocks, <= 120) fetches the three theta of block b and writes the eight subset sums T[8b + m];
@@ -140,7 +177,7 @@ __device__ __forceinline__ void block_dict_far_issue(const int32_t *far, int n, 
     }
 }
 template <int MODE, bool FAR_ISSUED = false>
-__device__ __forceinline__ void block_dict_issue(const Tile &T, int nd, const int32_t *far_tid, const double *theta, BlockDict &D) {
+__device__ __forceinline__ void block_dict_issue(const DTile &T, int nd, const int32_t *far_tid, const double *theta, BlockDict &D) {
     const int near_n = (int)T.near_n, far_n = nd - near_n, nb = (near_n + kBlk - 1) / kBlk;
     const bool near_thread = (int)threadIdx.x < emsar::kDictBlocks;
 #pragma unroll
@@ -162,7 +199,7 @@ __device__ __forceinline__ void block_dict_issue(const Tile &T, int nd, const in
         D.stid[j] = sl < near_n ? T.lo + sl : -1;
     }
 }
-__device__ __forceinline__ void block_dict_store(const Tile &T, const BlockDict &D, double *th_w, double *acc_w) {
+__device__ __forceinline__ void block_dict_store(const DTile &T, const BlockDict &D, double *th_w, double *acc_w) {
     constexpr int NE = emsar::kBlkEntries;
     const int nb = ((int)T.near_n + kBlk - 1) / kBlk;
     if ((int)threadIdx.x < emsar::kDictBlocks) {
@@ -188,7 +225,7 @@ __device__ __forceinline__ void block_dict_store(const Tile &T, const BlockDict 
         }
     }
 }
-__device__ __forceinline__ void block_dict_flush(const Tile &T, const BlockDict &D, const double *th_w, const double *acc_w, double *acc, double fx) {
+__device__ __forceinline__ void block_dict_flush(const DTile &T, const BlockDict &D, const double *th_w, const double *acc_w, double *acc, double fx) {
     constexpr int NE = emsar::kBlkEntries;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
@@ -329,7 +366,7 @@ __device__ __forceinline__ double sum_log_rows(const double (&S)[N], double *w_s
 
 template <bool WEIGHTED, int MODE, bool STAMP = false>
 __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__restrict__ tiles, const uint32_t *__restrict__ fwd,
-                                                              const uint32_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
+                                                              const uint32_t *__restrict__ bwd,
                                                               const int32_t *__restrict__ far_tid,
                                                               const int32_t *__restrict__ wgt,    // per row slot
                                                               const double *__restrict__ rowval,  // per row slot (MODE_SCATTER)
@@ -342,7 +379,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     unsigned long long ts[6];
     if (STAMP) ts[0] = stamp_now();
 
-    const Tile T = tiles[blockIdx.x];
+    const DTile T = tile_load(tiles + blockIdx.x);
     const int nd = (int)T.near_n + (int)T.far_n;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -354,27 +391,29 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
     // ---- issue every global load this wave needs first, in the order of use: dictionary values, 8 forward columns,
     //      8 backward segments.  One HBM round trip per tile; the rest of the pass touches LDS only.
     BlockDict D;
-    block_dict_issue<MODE>(T, nd, far_tid, theta, D);
+    block_dict_far_issue(far_tid + T.far_off, (int)T.far_n, D);       // the far list first, all of it: one round trip, then every theta in one more
     int4 A[8], B[8];
-    const int4 *e = nullptr, *b = nullptr;
-    int k = 0, m = 0;
-    unsigned coo_base = T.coo_off, coo_n = 0;
+    const int4 *e = reinterpret_cast<const int4 *>(fwd), *b = reinterpret_cast<const int4 *>(bwd);       // (a wave without a slice: one line, eight times)
+    int k = 1, m = 1;
     if (has_slice) {
         unsigned foff = 0, boff = 0;                 // KiB units (256 dwords) from the tile's bases
 #pragma unroll
         for (int s = 0; s < emsar::kTileSlices; s++) {
-            if (s < wave) { foff += T.k[s]; boff += T.m[s]; coo_base += T.coo_n[s]; }
-            if (s == wave) { k = T.k[s]; m = T.m[s]; coo_n = T.coo_n[s]; }
+            if (s < wave) { foff += T.k[s]; boff += T.m[s]; }
+            if (s == wave) { k = T.k[s]; m = T.m[s]; }
         }
         // everything above is wave-uniform; say so, or the loops below are compiled as divergent code
         k = __builtin_amdgcn_readfirstlane(k); m = __builtin_amdgcn_readfirstlane(m);
-        coo_n = __builtin_amdgcn_readfirstlane(coo_n); coo_base = __builtin_amdgcn_readfirstlane(coo_base);
         foff = __builtin_amdgcn_readfirstlane(foff); boff = __builtin_amdgcn_readfirstlane(boff);
         e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 4 + (size_t)foff * 256) + lane;
         b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 4 + (size_t)boff * 256) + lane;
-        if (MODE != MODE_SCATTER) load8_clamped(A, e, k < 8 ? k : 8);
-        if (m > 0) load8_clamped(B, b, m < 8 ? m : 8);
     }
+    // the index requests are unconditional and stand BEFORE the dictionary's theta, whose addresses wait for the far list: that wait is then
+    // vmcnt(16) on every path (hipcc merges paths with different numbers of requests into vmcnt(0))
+    if (MODE != MODE_SCATTER) load8_clamped(A, e, k < 8 ? k : 8);
+    load8_clamped(B, b, m < 8 ? m : 8);
+    block_dict_issue<MODE, true>(T, nd, nullptr, theta, D);
+    if (!has_slice) { k = 0; m = 0; }
     // ---- phase 0: the table of subset sums into LDS, the accumulators cleared ----
     block_dict_store(T, D, th_w, acc_w);
     if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;      // padding row of this wave's slice
@@ -432,11 +471,6 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
             bwd_sum_regs(B, n0, ws_base, acc_w, cur, part, fx.mass);
         }
         if (part != 0.0) tile_acc_add(acc_w, cur, part, fx.mass);
-        for (unsigned q = lane; q < coo_n; q += 64) {
-            const unsigned p = __builtin_nontemporal_load(&coo[coo_base + q]);
-            const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
-            if (v != 0.0) tile_acc_add(acc_w, (p >> 16) << 3, v, fx.mass);
-        }
     } else if (STAMP) ts[3] = stamp_now();
     if (STAMP) ts[4] = stamp_now();
     __syncthreads();
@@ -464,25 +498,23 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled(const Tile *__r
 struct TileWave {           // what one wave needs to know about its slice of a tile (all wave-uniform but e/b)
     const int4 *e, *b;
     int k, m, nd, slice;
-    unsigned coo_base, coo_n;
     bool has_slice;
 };
-__device__ __forceinline__ TileWave tile_wave(const Tile &T, int wave, int lane, const uint32_t *fwd, const uint32_t *bwd) {
+__device__ __forceinline__ TileWave tile_wave(const DTile &T, int wave, int lane, const uint32_t *fwd, const uint32_t *bwd) {
     TileWave W;
     W.nd = (int)T.near_n + (int)T.far_n;
     W.has_slice = wave >= 0 && wave < (int)T.n_slices;          // (wave = the slice index; -1: this wave has none in the tile)
     W.slice = wave;
-    W.e = nullptr; W.b = nullptr; W.k = 0; W.m = 0; W.coo_base = T.coo_off; W.coo_n = 0;
+    W.e = nullptr; W.b = nullptr; W.k = 0; W.m = 0;
     if (W.has_slice) {
         unsigned foff = 0, boff = 0;
-        int k = 0, m = 0; unsigned cn = 0, cb = T.coo_off;
+        int k = 0, m = 0;
 #pragma unroll
         for (int s = 0; s < emsar::kTileSlices; s++) {
-            if (s < wave) { foff += T.k[s]; boff += T.m[s]; cb += T.coo_n[s]; }
-            if (s == wave) { k = T.k[s]; m = T.m[s]; cn = T.coo_n[s]; }
+            if (s < wave) { foff += T.k[s]; boff += T.m[s]; }
+            if (s == wave) { k = T.k[s]; m = T.m[s]; }
         }
         W.k = __builtin_amdgcn_readfirstlane(k); W.m = __builtin_amdgcn_readfirstlane(m);
-        W.coo_n = __builtin_amdgcn_readfirstlane(cn); W.coo_base = __builtin_amdgcn_readfirstlane(cb);
         foff = __builtin_amdgcn_readfirstlane(foff); boff = __builtin_amdgcn_readfirstlane(boff);
         W.e = reinterpret_cast<const int4 *>(fwd + T.fwd_off / 4 + (size_t)foff * 256) + lane;
         W.b = reinterpret_cast<const int4 *>(bwd + T.bwd_off / 4 + (size_t)boff * 256) + lane;
@@ -490,7 +522,7 @@ __device__ __forceinline__ TileWave tile_wave(const Tile &T, int wave, int lane,
     return W;
 }
 // the slice of tile T that wave `wave` of a unit's workgroup takes, -1 if none (Tile::wave_of)
-__device__ __forceinline__ int unit_slice(const Tile &T, int wave) {
+__device__ __forceinline__ int unit_slice(const DTile &T, int wave) {
     int slice = -1;
 #pragma unroll
     for (int s = 0; s < emsar::kTileSlices; s++)
@@ -562,7 +594,7 @@ __device__ __forceinline__ void tile_e_step(const TileWave &W, int4 (&A)[8], siz
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], const uint32_t *coo, const double *w_s, double *acc_w, int lane, double fx) {
+__device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], const double *w_s, double *acc_w, int lane, double fx) {
     const unsigned ws_base = __builtin_amdgcn_readfirstlane(lds_byte_addr(w_s));
     unsigned cur = 0xFFFFFFFFu;
     double part = 0.0;
@@ -572,37 +604,34 @@ __device__ __forceinline__ void tile_m_step(const TileWave &W, int4 (&B)[8], con
         bwd_sum_regs<EMSAR_UM_BATCH>(B, n0, ws_base, acc_w, cur, part, fx);
     }
     if (part != 0.0) tile_acc_add(acc_w, cur, part, fx);
-    for (unsigned q = lane; q < W.coo_n; q += 64) {
-        const unsigned p = __builtin_nontemporal_load(&coo[W.coo_base + q]);
-        const double v = lds_at(w_s, (p & 0xFFFFu) << 3);
-        if (v != 0.0) tile_acc_add(acc_w, (p >> 16) << 3, v, fx);
-    }
+    (void)lane;
 }
 struct TileEnv {            // per-launch constants of the multi-tile kernel
     const Tile *tiles; int n_tiles, stride;
-    const uint32_t *fwd, *bwd, *coo; const int32_t *far_tid, *wgt; const double *theta; double *acc;
+    const uint32_t *fwd, *bwd; const int32_t *far_tid, *wgt; const double *theta; double *acc;
     double *th_w, *acc_w, *w_s; int lane, wave; double fx;
 };
 // stage I of N: tile `it` is in the registers (A, B in flight or landed, dictionary values in thv); while it is being
 // worked on, tile it + stride is requested into the registers as they fall free.  Straight-line code, no loop: hipcc
 // keeps loop-carried register arrays of this size in scratch.
 template <bool WEIGHTED, int MODE, int I, int N>
-__device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const Tile &T, const TileWave &W, int4 (&A)[8], int4 (&B)[8],
+__device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const DTile &T, const TileWave &W, int4 (&A)[8], int4 (&B)[8],
                                             BlockDict &D, LlAcc &ll) {
     block_dict_store(T, D, V.th_w, V.acc_w);
     const BlockDict Dcur = D;                     // tids of THIS tile's block, for its flush; D is refilled for the next tile below
     const int in = it + V.stride;
     const bool has_next = (I + 1 < N) && in < V.n_tiles;
-    const Tile Tn = V.tiles[has_next ? in : it];
+    const DTile Tn = tile_load(V.tiles + (has_next ? in : it));
     __syncthreads();
     if (W.has_slice)
         tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)V.wave * emsar::kTileSliceRows + V.lane, V.wgt, V.th_w, V.w_s, V.lane, ll);
     const TileWave Wn = tile_wave(Tn, V.wave, V.lane, V.fwd, V.bwd);
     if (has_next) {
         if (Wn.has_slice) load8_clamped(A, Wn.e, Wn.k < 8 ? Wn.k : 8);
-        block_dict_issue<MODE>(Tn, Wn.nd, V.far_tid, V.theta, D);
+        block_dict_far_issue(V.far_tid + Tn.far_off, (int)Tn.far_n, D);
+        block_dict_issue<MODE, true>(Tn, Wn.nd, nullptr, V.theta, D);
     }
-    if (W.has_slice) tile_m_step(W, B, V.coo, V.w_s, V.acc_w, V.lane, V.fx);
+    if (W.has_slice) tile_m_step(W, B, V.w_s, V.acc_w, V.lane, V.fx);
     if (has_next && Wn.has_slice && Wn.m > 0) load8_clamped(B, Wn.b, Wn.m < 8 ? Wn.m : 8);
     __syncthreads();
     block_dict_flush(T, Dcur, V.th_w, V.acc_w, V.acc, V.fx);
@@ -614,23 +643,24 @@ __device__ __forceinline__ void tiled_stage(const TileEnv &V, int it, const Tile
 
 template <bool WEIGHTED, int MODE, int N>
 __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Tile *__restrict__ tiles, int n_tiles, const uint32_t *__restrict__ fwd,
-                                                                    const uint32_t *__restrict__ bwd, const uint32_t *__restrict__ coo,
+                                                                    const uint32_t *__restrict__ bwd,
                                                                     const int32_t *__restrict__ far_tid, const int32_t *__restrict__ wgt,
                                                                     const double *__restrict__ theta, double *__restrict__ acc,
                                                                     double *__restrict__ ll_out, Fx fx) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double red[kTiledThreads / 64];
     TileEnv V;
-    V.tiles = tiles; V.n_tiles = n_tiles; V.stride = (int)gridDim.x; V.fwd = fwd; V.bwd = bwd; V.coo = coo; V.far_tid = far_tid; V.wgt = wgt;
+    V.tiles = tiles; V.n_tiles = n_tiles; V.stride = (int)gridDim.x; V.fwd = fwd; V.bwd = bwd; V.far_tid = far_tid; V.wgt = wgt;
     V.theta = theta; V.acc = acc; V.fx = fx.mass;
     V.lane = threadIdx.x & 63;
     V.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     V.th_w = lds; V.acc_w = lds + kTiledDictPad; V.w_s = lds + 2 * kTiledDictPad + V.wave * kTiledWr;
-    const Tile T = tiles[blockIdx.x];
+    const DTile T = tile_load(tiles + blockIdx.x);
     const TileWave W = tile_wave(T, V.wave, V.lane, fwd, bwd);
     BlockDict D;
     int4 A[8], B[8];
-    block_dict_issue<MODE>(T, W.nd, far_tid, theta, D);
+    block_dict_far_issue(far_tid + T.far_off, (int)T.far_n, D);
+    block_dict_issue<MODE, true>(T, W.nd, nullptr, theta, D);
     if (W.has_slice) {
         load8_clamped(A, W.e, W.k < 8 ? W.k : 8);
         if (W.m > 0) load8_clamped(B, W.b, W.m < 8 ? W.m : 8);
@@ -653,7 +683,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_multi(const Til
 template <bool WEIGHTED, int MODE, bool STAMP = false>
 __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile *__restrict__ utiles, int stride, const int32_t *__restrict__ far_tid,
                                                                    const uint32_t *__restrict__ fwd, const uint32_t *__restrict__ bwd,
-                                                                   const uint32_t *__restrict__ coo,
+                                                                   
                                                                    const int32_t *__restrict__ wgt, const double *__restrict__ theta,
                                                                    double *__restrict__ acc, double *__restrict__ ll_out, Fx fx,
                                                                    unsigned long long *stamps = nullptr) {
@@ -666,7 +696,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     if (STAMP) { ts0 = stamp_now(); tr0 = stamp_real(); }
     const Tile *tiles = utiles + (size_t)blockIdx.x * (size_t)stride;          // the unit's tiles: address known from the start
     BlockDict D;
-    Tile T = tiles[0];
+    DTile T = tile_load(tiles);
     // (a copy of the far list at a fixed stride per unit, requested together with the descriptor, was measured: 1 % SLOWER than
     // this dependent load -- the round trip it saves is not what the waves wait for, the unused tail of the list it reads is traffic)
     block_dict_far_issue(far_tid + T.far_off, (int)T.far_n, D);
@@ -675,13 +705,13 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     // which slice of a tile a wave takes is the layout's choice (Tile::wave_of: slices dealt to the waves by work)
     TileWave W = tile_wave(T, unit_slice(T, wave), lane, fwd, bwd);
     int4 A[8], B[8];
+    // the first forward columns go out BEFORE the dictionary's theta (whose addresses wait for the far list): unconditionally -- a wave without a
+    // slice asks for one line eight times -- so that the wait for the far list is vmcnt(8) on every path, not vmcnt(0)
+    load8_clamped(A, W.has_slice ? W.e : reinterpret_cast<const int4 *>(fwd), W.has_slice ? (W.k < 8 ? W.k : 8) : 1);
     block_dict_issue<MODE, true>(T, W.nd, nullptr, theta, D);
-    if (W.has_slice) {
-        load8_clamped(A, W.e, W.k < 8 ? W.k : 8);
-        if (W.m > 0) load8_clamped(B, W.b, W.m < 8 ? W.m : 8);
-    }
     if (lane < 8) w_s[emsar::kTileSliceRows + lane] = 0.0;
     block_dict_store(T, D, th_w, acc_w);
+    vm_loads_landed();
     if (STAMP) ts1 = stamp_now();
     __syncthreads();
     if (STAMP) ts2 = stamp_now();
@@ -690,16 +720,25 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
     for (int t = 0;; t++) {
         unsigned long long ta = 0, tb = 0;
         if (STAMP) ta = stamp_now();              // the tiles of the unit, one after the other, on the same table
-        if (W.has_slice) tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)W.slice * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
-        const Tile Tn = tiles[t + 1 < stride ? t + 1 : t];
+        // Order of the requests, and why they are unconditional inside a wave's branch: hipcc counts outstanding loads exactly (s_waitcnt
+        // vmcnt(n)) only along straight-line code; where two paths meet that issued different numbers of loads it waits for the larger
+        // share.  So this tile's backward segments are requested right before its E-step (in flight during it) and the next tile's forward
+        // columns right before its M-step (in flight during it), both inside the has_slice branch; when there is no next tile the wave
+        // requests eight copies of one 16-byte line instead (every lane the same address) so that the count the M-step waits on is the same.
+        if (W.has_slice) {
+            load8_clamped(B, W.b, W.m < 8 ? W.m : 8);          // (a slice has rows, a row has entries: m >= 1, check_tiled_extents)
+            tile_e_step<WEIGHTED, MODE>(W, A, (size_t)T.row_base + (size_t)W.slice * emsar::kTileSliceRows + lane, wgt, th_w, w_s, lane, ll);
+        }
+        const DTile Tn = tile_load(tiles + (t + 1 < stride ? t + 1 : t));
         const bool more = t + 1 < stride && Tn.n_slices > 0;
         TileWave Wn = tile_wave(Tn, unit_slice(Tn, wave), lane, fwd, bwd);
         if (!more) Wn.has_slice = false;
         if (STAMP) tb = stamp_now();
-        if (Wn.has_slice) load8_clamped(A, Wn.e, Wn.k < 8 ? Wn.k : 8);        // the next tile's forward columns during this one's M-step
-        if (W.has_slice) tile_m_step(W, B, coo, w_s, acc_w, lane, fx.mass);
+        if (W.has_slice) {
+            load8_clamped(A, Wn.has_slice ? Wn.e : reinterpret_cast<const int4 *>(fwd), Wn.has_slice ? (Wn.k < 8 ? Wn.k : 8) : 1);
+            tile_m_step(W, B, w_s, acc_w, lane, fx.mass);
+        } else if (Wn.has_slice) load8_clamped(A, Wn.e, Wn.k < 8 ? Wn.k : 8);
         if (STAMP) { const unsigned long long tc = stamp_now(); te += tb - ta; tm += tc - tb; }
-        if (Wn.has_slice && Wn.m > 0) load8_clamped(B, Wn.b, Wn.m < 8 ? Wn.m : 8);
         T = Tn; W = Wn;
         n_done = t + 1;
         if (!more) break;
@@ -717,7 +756,7 @@ __global__ __launch_bounds__(kTiledThreads, 4) void k_pass_tiled_unit(const Tile
         const int sl = (int)threadIdx.x + j * kTiledThreads;
         D.stid[j] = sl < dict_near_n ? dict_lo + sl : -1;
     }
-    T.near_n = (uint16_t)dict_near_n;            // (T is the last tile read by now: an absent one when the unit has fewer tiles than the stride)
+    T.near_n = (uint32_t)dict_near_n;            // (T is the last tile read by now: an absent one when the unit has fewer tiles than the stride)
     block_dict_flush(T, D, th_w, acc_w, acc, fx.mass);
     if (STAMP && lane == 0) {      // [unit][wave]: descriptor + dictionary + first loads, barrier, E-steps, M-steps, barrier, flush, tiles
         unsigned long long *o = stamps + ((size_t)blockIdx.x * (kTiledThreads / 64) + wave) * 8;

@@ -97,7 +97,7 @@ inline uint32_t entry_swz(uint32_t b) { return EMSAR_SWZ ? (b & (uint32_t)(kBlkE
 inline uint32_t entry_code(uint32_t b, uint32_t m) { return b * (uint32_t)kBlkEntries + (m ^ entry_swz(b)); }
 inline uint32_t entry_mask(uint32_t e) { return (e & (uint32_t)(kBlkEntries - 1)) ^ entry_swz(e >> kBlk); }
 constexpr int kUnitMaxTiles = 4;       // tiles that may share one dictionary
-constexpr int kDenseMin = 1;           // columns with fewer entries in a slice use the COO list (1 = none: with block entries the COO path --
+constexpr int kDenseMin = 1;           // columns with fewer entries in a slice would use a COO list; MUST stay 1, the kernels read none (with block entries the COO path --
                                        // a load, an LDS read and an LDS atomic per entry -- costs more than a mostly empty segment: 4 / 2 / 1 -> 0.139 / 0.133 / 0.127 ms)
 // the entries (block * 8 + mask) of one row from its dictionary slots (any order; a slot that occurs twice -- an internal repeat
 // of the transcript -- opens a second entry of the same block: a subset holds a transcript once)
@@ -219,10 +219,12 @@ inline int check_tiled_extents(const TiledLayout &L) {
         size_t foff = (size_t)(T.fwd_off / 4), boff = (size_t)(T.bwd_off / 4), coff = T.coo_off;
         for (int s = 0; s < kTileSlices; s++) {
             if (s >= T.n_slices) { if (T.k[s] || T.m[s] || T.coo_n[s]) return -27; continue; }
+            if (T.coo_n[s]) return -27;                          // the kernels no longer read a COO list (kDenseMin = 1: the builder makes none)
             uint8_t &u = slice_used[(size_t)T.row_base / (size_t)kTileSliceRows + (size_t)s];
             if (u) return -25;                                                  // two tiles on one slice of row slots
             u = 1;
             if (T.k[s] > kMaxRowLen) return -27;
+            if (T.k[s] < 1 || T.m[s] < 1) return -27;            // a slice has rows and a row has entries: the kernels request column 0 and segment 0 of every slice without asking
             const size_t fw = (size_t)T.k[s] * kSliceDwords, bw = (size_t)T.m[s] * 64 * 4;
             if (foff + fw > nf || boff + bw > nb || coff + T.coo_n[s] > nc) return -28;
             // an entry names a block and a subset of it: every slot of the subset must exist in the tile's dictionary
