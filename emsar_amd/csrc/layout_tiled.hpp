@@ -881,6 +881,14 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
     if (dbg_t) fprintf(stderr, "build_tiled: total %.0f ms; %zu tiles in %zu units, %lld slices, %lld entries in %lld padded operands, %lld far\n", t_ms(tp0, t_now()),
                        out.tiles.size(), out.unit_first.empty() ? (size_t)0 : out.unit_first.size() - 1, (long long)out.n_fslices,
                        (long long)out.tiled_entries, (long long)out.padded_slots, (long long)out.far_entries);
+    if (dbg_t) {        // batches of 8 columns / segments per slice: what the E- and M-steps request after their first batch
+        double n = 0, sk = 0, sm = 0, k8 = 0, k16 = 0, m8 = 0, m16 = 0, m24 = 0;
+        for (const Tile &T : out.tiles) for (int s2 = 0; s2 < (int)T.n_slices; s2++) {
+            n += 1; sk += T.k[s2]; sm += T.m[s2]; k8 += T.k[s2] > 8; k16 += T.k[s2] > 16; m8 += T.m[s2] > 8; m16 += T.m[s2] > 16; m24 += T.m[s2] > 24;
+        }
+        if (n > 0) fprintf(stderr, "build_tiled: per slice %.2f forward columns (%.0f %% > 8, %.0f %% > 16), %.2f backward segments per lane (%.0f %% > 8, %.0f %% > 16, %.0f %% > 24)\n",
+                           sk / n, 100 * k8 / n, 100 * k16 / n, sm / n, 100 * m8 / n, 100 * m16 / n, 100 * m24 / n);
+    }
     const int ext = check_tiled_extents(out);       // nothing reaches the device unless every descriptor stays inside its arrays
     return ext == 0 ? 0 : ext;
 }
