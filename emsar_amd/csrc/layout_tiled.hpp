@@ -868,6 +868,16 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
             std::stable_sort(cut.begin() + (std::ptrdiff_t)keep, cut.end(), [](const Unit &a, const Unit &b) { return a.w > b.w; });
             units.swap(cut);
         }
+        if (dbg_t && !units.empty()) {     // how well the units fill 1024 workgroup slots in this (longest-first) order: greedy makespan over the mean load
+            for (int64_t c : {(int64_t)0, (int64_t)20000}) {     // c: a fixed cost per unit (descriptor, dictionary, flush) in the units of `work`
+                std::vector<int64_t> slot(1024, 0);
+                int64_t tot = 0;
+                for (const Unit &u : units) { auto it = std::min_element(slot.begin(), slot.end()); *it += u.w + c; tot += u.w; }
+                const int64_t mk = *std::max_element(slot.begin(), slot.end());
+                fprintf(stderr, "build_tiled: %zu units, work max %lld, median %lld, min %lld; with %lld per unit on top: greedy makespan on 1024 slots %.0f = %.3f of the mean load\n",
+                        units.size(), (long long)units.front().w, (long long)units[units.size() / 2].w, (long long)units.back().w, (long long)c, (double)mk, (double)mk * 1024.0 / (double)tot);
+            }
+        }
         std::vector<Tile> sorted_tiles;
         sorted_tiles.reserve(out.tiles.size());
         out.unit_first.clear();
