@@ -74,7 +74,7 @@ def _roofline(args, structure, info, per_pass_s, weighted=False, tag=""):
     moves a third of those bytes, so that figure may exceed the HBM peak -- it is not a roofline fraction."""
     layout_name = {1: "csr", 3: "tiled", 259: "tiled+merged-rows"}[info["layout"]] + tag
     tr = _traffic(args, structure, layout_name)
-    r = {"bound": "latency", "bound_evidence": "PMC: HBM below its copy ceiling, SQ_WAIT_ANY > 50 % of wave cycles, LDS pipe < 50 % busy (profiles/)",
+    r = {"bound": "latency", "bound_evidence": "PMC: HBM below its copy ceiling, waves waiting (SQ_WAIT_ANY) 41-49 % of their cycles, LDS pipe < 50 % busy, VALU ~20 % (profiles/*_pmc.txt)",
          "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
          "kernel": _kernel_name(info, weighted) + "+k_update", "device_ms_per_pass": per_pass_s * 1e3,
          "algorithmic_bytes_per_pass": info["bytes_per_pass"], "stored_bytes_per_pass": info["stored_bytes_per_pass"],
