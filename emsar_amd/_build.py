@@ -64,11 +64,11 @@ def build_host(force=False):
         return None
     deps = srcs + [os.path.join(hdir, "emsar_host.h"), os.path.join(ROOT, "include", "emsar_hip.h")]
     if force or _stale(HOST_SO, deps):
-        _run(["gcc"] + C_FLAGS + ["-shared", "-o", HOST_SO] + srcs + ["-lm", "-lz"])
+        _run(["gcc"] + C_FLAGS + ["-shared", "-o", HOST_SO] + srcs + ["-lm", "-lz", "-ldl"])
     main = os.path.join(hdir, "emsar_hip_main.c")
     if os.path.exists(main) and (force or _stale(CLI, deps + [main, HIP_SO])):
         _run(["gcc"] + C_FLAGS + ["-o", CLI, main, "-I" + os.path.join(ROOT, "include"), "-L" + PKG,
-              "-lemsar_host", "-lemsar_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lz", "-lpthread"])
+              "-lemsar_host", "-lemsar_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lz", "-lpthread", "-ldl"])
     return HOST_SO
 
 

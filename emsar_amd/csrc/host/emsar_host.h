@@ -67,6 +67,7 @@ struct emsar_pbgzf;
 struct emsar_pbgzf *emsar_pbgzf_open(const char *path);
 long emsar_pbgzf_read(struct emsar_pbgzf *p, void *dst, size_t n);
 void emsar_pbgzf_close(struct emsar_pbgzf *p);
+const char *emsar_pbgzf_engine(void);   /* "libdeflate" when libdeflate.so.0 could be loaded (EMSAR_HOST_INFLATE=zlib: never), else "zlib" */
 
 /* Optional collapse of read-level rows OUTSIDE this library (emsar_hip_collapse_rows has exactly this signature behind a
  * context): rows with the same multiset of ids become one row with the number of members as its weight; ids sorted in the

@@ -227,3 +227,41 @@ def test_many_batches(tmp_path, monkeypatch):
         lib.emsar_pbgzf_close(h)
         assert bytes(out) == payload
     assert lib.emsar_pbgzf_open(os.path.join(os.path.dirname(__file__), "golden", "syn2k_se", "reads.bowtie.gz").encode()) is None   # plain gzip
+
+
+def test_both_inflate_engines_read_the_same_bytes(bam_case):
+    """pbgzf.c inflates with libdeflate when the system has its shared library and with zlib otherwise (or when
+    EMSAR_HOST_INFLATE=zlib says so).  The engine is chosen once per process: two child processes, same file, same counts;
+    a damaged block is an error under both."""
+    import json
+    import subprocess
+    _, bam, want, d = bam_case
+    fx = get_fixture("syn2k_se")
+    raw = bytearray(open(bam, "rb").read())
+    bsize = raw[16] | (raw[17] << 8)
+    raw[bsize + 1 + 40] ^= 0xFF
+    bad = str(d / "crc2.bam")
+    open(bad, "wb").write(bytes(raw))
+    code = ("import sys, json, ctypes, zlib\n"
+            "sys.path.insert(0, %r)\n"
+            "from emsar_amd import hostlib as HL\n"
+            "lib = HL.lib(); lib.emsar_pbgzf_engine.restype = ctypes.c_char_p\n"
+            "r = HL.HostRsh(%r)\n"
+            "c = r.count(%r, fmt=2)\n"
+            "try:\n"
+            "    r.count(%r, fmt=2); err = False\n"
+            "except HL.HostError:\n"
+            "    err = True\n"
+            "print(json.dumps({'engine': lib.emsar_pbgzf_engine().decode(), 'crc': zlib.crc32(c.R.tobytes()), 'total': int(c.total_reads), 'damaged_is_error': err}))\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(fx.dir, "index.rsh"), bam, bad))
+    out = {}
+    for eng in ("", "zlib"):
+        env = dict(os.environ, EMSAR_HOST_INFLATE=eng, EMSAR_HOST_THREADS="3")
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        out[eng] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["zlib"]["engine"] == "zlib"
+    assert out[""]["engine"] in ("libdeflate", "zlib")          # libdeflate where libdeflate.so.0 exists (this image), zlib elsewhere
+    import zlib
+    for o in out.values():
+        assert o["crc"] == zlib.crc32(want.R.tobytes()) and o["total"] == want.total_reads and o["damaged_is_error"]
