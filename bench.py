@@ -68,7 +68,7 @@ def _kernel_name(info, weighted):
     return "k_pass_tiled"
 
 
-def _roofline(args, structure, info, per_pass_s, weighted=False, tag=""):
+def _roofline(args, structure, info, per_pass_s, weighted=False, tag="", live=None, live_why=None):
     """frac = HBM bytes the counters saw per launch / device time per pass / 8 TB/s -- a fraction of the peak the memory system really
     delivered.  The SURVEY 8d formula (what a CSR walk would stream) is reported as csr_equivalent_GBps: the TILED layout stores and
     moves a third of those bytes, so that figure may exceed the HBM peak -- it is not a roofline fraction."""
@@ -80,7 +80,18 @@ def _roofline(args, structure, info, per_pass_s, weighted=False, tag=""):
          "algorithmic_bytes_per_pass": info["bytes_per_pass"], "stored_bytes_per_pass": info["stored_bytes_per_pass"],
          "csr_equivalent_GBps": info["bytes_per_pass"] / per_pass_s / 1e9,
          "stored_GBps": info["stored_bytes_per_pass"] / per_pass_s / 1e9}
-    if tr is not None:
+    if live is not None:                       # observed by this very run (live_traffic): two rocprofv3 --pmc child processes on this box
+        r["traffic"] = live["hbm_bytes_per_launch"]
+        r["traffic_source"] = ("observed in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child processes, 3 passes of "
+                               "this matrix each, %d dispatches of the pass kernel): FETCH_SIZE %.0f KB x 2 (gfx950 correction) + WRITE_SIZE %.0f KB; %s s"
+                               % (live["FETCH_SIZE_dispatches"], live["FETCH_SIZE"], live["WRITE_SIZE"], live.get("seconds")))
+        if tr is not None:
+            r["traffic_committed"] = tr["hbm_bytes_per_launch"]      # profiles/traffic.json, for comparison
+        r["achieved"] = r["traffic"] / per_pass_s / 1e9
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+    elif tr is not None:
+        if live_why and live_why != "not requested":
+            r["live_pmc_failed"] = live_why
         r["traffic"] = tr["hbm_bytes_per_launch"]
         r["traffic_source"] = "profiles/traffic.json (rocprofv3 PMC run of this kernel and workload: %s)" % tr.get("profile", "")
         r["achieved"] = tr["hbm_bytes_per_launch"] / per_pass_s / 1e9
@@ -97,7 +108,75 @@ def _layout_stats(info):
     return d
 
 
+def _pmc_child(cache):
+    """Internal (bench.py --pmc-child FILE): the profiled process of live_traffic() -- the matrix of the parent from its cache file, a few
+    passes of the same kernel, nothing else (no torch, no JSON)."""
+    import numpy as np
+    from emsar_amd import EmsarHip
+    z = np.load(cache)
+    with EmsarHip(int(z["device"])) as dev:
+        if int(z["weighted"]):
+            dev.upload_structure(int(z["n_tx"]), z["row_ptr"], z["col_idx"], int(z["layout"]))
+            dev.upload_sample(z["wgt"], None, z["den"])
+        else:
+            dev.upload_structure(int(z["n_tx"]), z["row_ptr"], z["col_idx"], int(z["layout"]), merge_rows=bool(z["merge_rows"]))
+            dev.upload_sample(None, None, z["den"])
+        dev.run_passes(1)
+        dev.run_passes(3)
+
+
+def live_traffic(device, n_tx, row_ptr, col_idx, den, layout, wgt=None, merge_rows=False, kernel_pattern="k_pass_tiled", timeout_s=240):
+    """HBM bytes per launch of the pass kernel, OBSERVED in this run: two child processes under `rocprofv3 --kernel-trace --pmc <counter>`
+    (FETCH_SIZE; WRITE_SIZE -- separate passes, as /opt/skills/guides/MI355X_MICROARCH.md's HBM section prescribes) run three passes of
+    the same matrix; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (KB counters; FETCH_SIZE doubled: the guide's gfx950 correction for
+    wide streaming reads), mean over the dispatches of the kernel.  None (and the reason) when the profiler is not there or fails:
+    the caller then falls back to the committed profiles/traffic.json."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    work = tempfile.mkdtemp(prefix="emsar_pmc_", dir="/tmp")
+    cache = os.path.join(tempfile.mkdtemp(prefix="emsar_pmc_", dir=shm), "m.npz") if shm else os.path.join(work, "m.npz")
+    got = {}
+    try:
+        np.savez(cache, device=device, n_tx=n_tx, row_ptr=row_ptr, col_idx=col_idx, den=den, layout=layout, weighted=int(wgt is not None),
+                 wgt=wgt if wgt is not None else np.zeros(1, dtype=np.int32), merge_rows=int(merge_rows))
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", cache]
+            r = subprocess.run(cmd, cwd=work, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited %d: %s" % (counter, r.returncode, r.stdout[-300:].replace("\n", " | "))
+            per = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_pattern in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None, "no %s rows for %s in the profiler's output" % (counter, kernel_pattern)
+            got[counter] = sum(per.values()) / len(per)
+            got[counter + "_dispatches"] = len(per)
+    except Exception as e:                                  # the roofline then quotes the committed measurement
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+        if shm:
+            shutil.rmtree(os.path.dirname(cache), ignore_errors=True)
+    got["hbm_bytes_per_launch"] = int((2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
+    return got, None
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--pmc-child":
+        return _pmc_child(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -110,6 +189,9 @@ def main():
     ap.add_argument("--layout", default="auto", choices=["auto", "csr", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip workload_variants and the collapsed form (profiling runs)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child processes that observe the pass kernel's HBM traffic in this run; "
+                         "roofline.traffic then comes from profiles/traffic.json (N > 1 and profiling runs always do)")
     ap.add_argument("--xfam", type=float, default=None, help="experiment: override the config's share of cross-family reads")
     ap.add_argument("--merge-rows", action="store_true",
                     help="store identical rows once (read -> segment collapse at upload); NOT the headline configuration")
@@ -196,6 +278,18 @@ def main():
         solve = {"tol": args.solve, "abs_floor": args.solve_floor, "passes": st.iters, "converged": bool(st.converged), "seconds": dt,
                  "kernel_ms": st.kernel_ms, "iters_per_s_to_convergence": st.iters / dt, "loglik": st.loglik, "final_delta": st.final_delta,
                  "mass_conserved": bool(abs(float((th_s * s["den"]).sum()) - s["n_reads"]) <= 1e-8 * s["n_reads"])}
+    live, live_why = None, "not requested"
+    under_profiler = any(k.startswith("ROCPROF") for k in os.environ)          # this process is itself being profiled (tools/prof_round.sh)
+    if nnz > 1.5e9 and not args.no_live_pmc:
+        live_why = "skipped above 1.5e9 nonzeros (the matrix would be written out and uploaded twice more)"
+    elif rank == 0 and world == 1 and not args.no_live_pmc and info["layout"] != 1 and not under_profiler:
+        t0 = time.time()
+        if args.collapsed:
+            live, live_why = live_traffic(local_rank, s["n_tx"], rp_c, ci_c, s["den"], layout, wgt=w_c)
+        else:
+            live, live_why = live_traffic(local_rank, s["n_tx"], s["row_ptr"], s["col_idx"], s["den"], layout, merge_rows=args.merge_rows)
+        if live is not None:
+            live["seconds"] = round(time.time() - t0, 1)
     out = None
     if rank == 0:
         per_pass_s = kernel_ms / 1e3 / args.steps
@@ -209,7 +303,8 @@ def main():
                        "structure": args.structure,
                        "layout": {1: "csr", 3: "tiled", 259: "tiled+merged-rows"}[info["layout"]], "parallelism": "1 sample per GPU x %d" % world},
             "read_alignments_per_s": world * nnz * args.steps / wall,
-            "roofline": _roofline(args, args.structure, info, per_pass_s, weighted=args.collapsed, tag="+collapsed" if args.collapsed else ""),
+            "roofline": _roofline(args, args.structure, info, per_pass_s, weighted=args.collapsed, tag="+collapsed" if args.collapsed else "",
+                                  live=live, live_why=live_why),
             "layout_stats": _layout_stats(info),
             "setup_s": {"generate": round(t_gen, 2), "upload_and_layout": round(t_up, 2)},
             "mass_conserved": ok,

@@ -7,7 +7,7 @@ O=$R/gpurun_out/prof_${1:-r02}
 mkdir -p $O
 cd $R
 S=${2:-family}; X=${3:-}
-B="--no-cpu-baseline --solve 0 --no-variants --structure $S $X"
+B="--no-live-pmc --no-cpu-baseline --solve 0 --no-variants --structure $S $X"
 python bench.py --steps 20 --warmup 5 --structure $S $X > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-400
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --steps 100 --warmup 10 $B > $O/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --spinup 0 $B > $O/p1.log 2>&1
