@@ -152,9 +152,20 @@ def live_traffic(device, n_tx, row_ptr, col_idx, den, layout, wgt=None, merge_ro
             out = os.path.join(work, counter)
             cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", cache]
-            r = subprocess.run(cmd, cwd=work, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
-            if r.returncode != 0:
-                return None, "rocprofv3 --pmc %s exited %d: %s" % (counter, r.returncode, r.stdout[-300:].replace("\n", " | "))
+            # a session of its own: on a timeout the profiler AND the profiled process are ended (the exact group this call started)
+            pr = subprocess.Popen(cmd, cwd=work, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+            try:
+                log, _ = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.communicate()
+                return None, "rocprofv3 --pmc %s did not finish in %d s" % (counter, timeout_s)
+            if pr.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited %d: %s" % (counter, pr.returncode, log[-300:].replace("\n", " | "))
             per = {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
