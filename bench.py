@@ -125,6 +125,20 @@ def _pmc_child(cache):
         dev.run_passes(3)
 
 
+LIVE = {"on": False, "device": 0}        # set by main(): rank 0 of a one-GPU run that is not itself being profiled
+
+
+def _live_for(n_tx, row_ptr, col_idx, den, wgt=None):
+    """live_traffic() for one of the other forms of the workload, when the run observes traffic at all"""
+    if not LIVE["on"] or len(col_idx) > 1.5e9:
+        return None, "not requested"
+    t0 = time.time()
+    got, why = live_traffic(LIVE["device"], n_tx, row_ptr, col_idx, den, LIVE["layout"], wgt=wgt)
+    if got is not None:
+        got["seconds"] = round(time.time() - t0, 1)
+    return got, why
+
+
 def live_traffic(device, n_tx, row_ptr, col_idx, den, layout, wgt=None, merge_rows=False, kernel_pattern="k_pass_tiled", timeout_s=240):
     """HBM bytes per launch of the pass kernel, OBSERVED in this run: two child processes under `rocprofv3 --kernel-trace --pmc <counter>`
     (FETCH_SIZE; WRITE_SIZE -- separate passes, as /opt/skills/guides/MI355X_MICROARCH.md's HBM section prescribes) run three passes of
@@ -301,6 +315,7 @@ def main():
             live, live_why = live_traffic(local_rank, s["n_tx"], s["row_ptr"], s["col_idx"], s["den"], layout, merge_rows=args.merge_rows)
         if live is not None:
             live["seconds"] = round(time.time() - t0, 1)
+        LIVE.update(on=live is not None, device=local_rank, layout=layout)       # the other forms below observe theirs too, if this one could
     out = None
     if rank == 0:
         per_pass_s = kernel_ms / 1e3 / args.steps
@@ -329,7 +344,8 @@ def main():
     # ---- the other forms of the same config (rank 0, N = 1): the other row laws, and the collapsed (segment-level) form -----------
     if rank == 0 and world == 1 and not args.no_variants and not args.collapsed and not args.merge_rows:
         variants = {args.structure: {"ms_per_pass": kernel_ms / args.steps, "nnz": nnz, **_variant_stats(info),
-                                     "roofline_frac": out["roofline"]["frac"]}}
+                                     "roofline_frac": out["roofline"]["frac"], "hbm_traffic_bytes": out["roofline"]["traffic"],
+                                     "traffic_observed_in_this_run": live is not None}}
         out["collapsed_form"] = collapsed_form(args, dev, s, info)
         for st_name in ("window", "family", "family_shuffled"):
             if st_name in variants:
@@ -379,9 +395,10 @@ def time_variant(args, dev, v, name, passes=100):
     info = dev.info()
     _spin(dev, 0.5)                       # the card idled while the host built the layout: clocks up again before timing
     ms = dev.run_passes(passes) / passes
-    r = _roofline(args, name, info, ms / 1e3)
+    live, why = _live_for(v["n_tx"], v["row_ptr"], v["col_idx"], v["den"]) if info["layout"] != 1 else (None, "not requested")
+    r = _roofline(args, name, info, ms / 1e3, live=live, live_why=why)
     return {"ms_per_pass": ms, "nnz": int(len(v["col_idx"])), **_variant_stats(info), "upload_and_layout_s": round(t_up, 2),
-            "roofline_frac": r["frac"], "hbm_traffic_bytes": r["traffic"]}
+            "roofline_frac": r["frac"], "hbm_traffic_bytes": r["traffic"], "traffic_observed_in_this_run": live is not None}
 
 
 def collapsed_form(args, dev, s, info_read_level, passes=100):
@@ -400,11 +417,12 @@ def collapsed_form(args, dev, s, info_read_level, passes=100):
     ms = dev.run_passes(passes) / passes
     th = dev.get_theta()
     mass = float((th * s["den"]).sum())
-    r = _roofline(args, args.structure, info, ms / 1e3, weighted=True, tag="+collapsed")
+    live, why = _live_for(s["n_tx"], rp, ci, s["den"], wgt=w) if info["layout"] != 1 else (None, "not requested")
+    r = _roofline(args, args.structure, info, ms / 1e3, weighted=True, tag="+collapsed", live=live, live_why=why)
     return {"rows": int(len(w)), "nnz": int(len(ci)), "reads": int(w.sum()), "ms_per_pass": ms, "iters_per_s": 1e3 / ms,
             "collapse_kernel_ms": cst.kernel_ms, "upload_and_layout_s": round(t_up, 2), "kernel": r["kernel"],
             "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_pass",
-                                           "stored_bytes_per_pass", "stored_GBps", "csr_equivalent_GBps")},
+                                           "stored_bytes_per_pass", "stored_GBps", "csr_equivalent_GBps", "traffic_source") if k in r},
             **_variant_stats(info), "mass_conserved": bool(abs(mass - s["n_reads"]) <= 1e-8 * s["n_reads"])}
 
 
