@@ -259,6 +259,7 @@ def main():
     t0 = time.time()
     collapsed_main = None
     if args.collapsed:
+        dev.collapse_rows(s["n_tx"], s["row_ptr"][:1001], s["col_idx"][:int(s["row_ptr"][1000])], want_map=False)     # loads the kernels' code objects
         rp_c, ci_c, w_c, _, cst = dev.collapse_rows(s["n_tx"], s["row_ptr"], s["col_idx"], want_map=False)
         collapsed_main = {"rows": int(len(w_c)), "nnz": int(len(ci_c)), "collapse_kernel_ms": cst.kernel_ms}
         dev.upload_structure(s["n_tx"], rp_c, ci_c, layout)
