@@ -342,6 +342,21 @@ static int mate_id_len(const char *a, const char *b) {
 
 #define FAIL(code, ...) do { if (err) snprintf(err, errlen, __VA_ARGS__); rc = (code); goto done; } while (0)
 
+/* a worker's view of a batch of whole text lines already in memory (count_text_parallel): the lines are NUL-terminated in place,
+ * with the line reader's rules (trailing newline and a CR before it stripped; a last line without a newline is a line) */
+typedef struct { char *p; size_t n, pos; } memtext;
+static char *mt_next(memtext *m) {
+    if (m->pos >= m->n) return NULL;
+    char *start = m->p + m->pos;
+    char *nl = (char *)memchr(start, '\n', m->n - m->pos);
+    size_t len;
+    if (nl) { len = (size_t)(nl - start); m->pos += len + 1; }
+    else { len = m->n - m->pos; m->pos = m->n; }                     /* (the batch buffer has one spare byte behind n) */
+    start[len] = 0;
+    if (len && start[len - 1] == '\r') start[len - 1] = 0;
+    return start;
+}
+
 /* One worker of emsar_count_alignments: the read groups of a byte range [begin, end) of a plain text file (end < 0: to
  * the end of the file; begin = 0 and end < 0: the whole input, any format).  Groups are runs of KEPT records with one
  * read id (filtered records do not break a run, emsar_functions.c:748,815), so the ranges are stitched on kept
@@ -363,7 +378,9 @@ static emsar_counts *counts_new(const emsar_rsh *r) {
 /* mem_bam / acc (both or neither): the records of one batch of a BAM file, already in memory and starting on a read
  * group, counted into the caller's accumulator (count_bam_parallel) */
 static int count_range(const emsar_rsh *r, const char *path, const emsar_aln_opts *o, int64_t begin, int64_t end,
-                       emsar_counts **out, int *got_group, char *err, size_t errlen, bamreader *mem_bam, emsar_counts *acc) {
+                       emsar_counts **out, int *got_group, char *err, size_t errlen, bamreader *mem_bam, emsar_counts *acc, memtext *mem_txt) {
+#define NEXT_LINE() (mem_txt ? mt_next(mem_txt) : emsar_lr_next(lr))
+#define LINE_OFFSET() (mem_txt ? (int64_t)0 : emsar_lr_offset(lr))
     int rc = EMSAR_HOST_OK;
     *out = NULL; *got_group = 0;
     emsar_counts *c = acc ? acc : counts_new(r);
@@ -378,6 +395,7 @@ static int count_range(const emsar_rsh *r, const char *path, const emsar_aln_opt
     char *line2 = NULL;
     if (!c) { if (err) snprintf(err, errlen, "out of memory"); return EMSAR_HOST_ERR_OOM; }
     if (mem_bam) bam = mem_bam;
+    else if (mem_txt) { /* lines come from the batch */ }
     else if (o->format == 2) {
         bam = bam_open(path, r);
         if (!bam) FAIL(EMSAR_HOST_ERR_IO, "can't open BAM file %s", path);
@@ -395,7 +413,7 @@ static int count_range(const emsar_rsh *r, const char *path, const emsar_aln_opt
         if (o->format != 0) {                                        /* ---------- SAM text / BAM ---------- */
             int st;
             if (bam) st = bam_next(bam, &r1);
-            else { line = emsar_lr_next(lr); if (line) rec_off = emsar_lr_offset(lr); st = line ? sam_parse(line, &r1) : -2; if (st == 0) continue; if (st == -2) st = 0; }
+            else { line = NEXT_LINE(); if (line) rec_off = LINE_OFFSET(); st = line ? sam_parse(line, &r1) : -2; if (st == 0) continue; if (st == -2) st = 0; }
             if (st == 0) break;
             if (st < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "malformed %s record", bam ? "BAM" : "SAM");
             if (r1.unaligned) continue;                               /* core.tid == -1 (359, 515) */
@@ -409,7 +427,7 @@ static int count_range(const emsar_rsh *r, const char *path, const emsar_aln_opt
                 }
             } else {                                                  /* mate on the next record (514-520) */
                 if (bam) st = bam_next(bam, &r2);
-                else { char *l2 = emsar_lr_next(lr); st = l2 ? sam_parse(l2, &r2) : 0; }
+                else { char *l2 = NEXT_LINE(); st = l2 ? sam_parse(l2, &r2) : 0; }
                 if (st == 0) break;
                 if (st < 0) FAIL(EMSAR_HOST_ERR_FORMAT, "malformed %s record", bam ? "BAM" : "SAM");
                 int32_t tid = r1.tid >= 0 ? r1.tid : emsar_rsh_tid_of(r, r1.rname);
@@ -426,10 +444,10 @@ static int count_range(const emsar_rsh *r, const char *path, const emsar_aln_opt
                 if (p2 > p1) { x.fraglen = p2 - p1 + c->readlength; x.pos = p1; keep = !(o->strand == '-') && (s1 == '+' && s2 == '-'); }
                 else { x.fraglen = p1 - p2 + c->readlength; x.pos = p2; keep = !(o->strand == '+') && (s1 == '-' && s2 == '+'); }
             }
-        } else if (!(line = emsar_lr_next(lr))) {
+        } else if (!(line = NEXT_LINE())) {
             break;
         } else if (!o->pe) {                                          /* ---------- default bowtie, single-end (552-587) ---------- */
-            rec_off = emsar_lr_offset(lr);
+            rec_off = LINE_OFFSET();
             char *f[9];
             int nf = split_tabs(line, f, 9);
             if (nf < 7) FAIL(EMSAR_HOST_ERR_FORMAT, "input alignment file doesn't look like a bowtie output file");
@@ -446,12 +464,12 @@ static int count_range(const emsar_rsh *r, const char *path, const emsar_aln_opt
                 const char *tab = strchr(line, '\t');
                 if (tab && tab - line >= 2 && tab[-2] == '/' && tab[-1] == '2') continue;
             }
-            rec_off = emsar_lr_offset(lr);
+            rec_off = LINE_OFFSET();
             size_t n1 = strlen(line) + 1;
             char *keep1 = (char *)realloc(line2, n1);
             if (!keep1) FAIL(EMSAR_HOST_ERR_OOM, "out of memory");
             line2 = keep1; memcpy(line2, line, n1);                   /* record 1 survives the next read */
-            char *l2 = emsar_lr_next(lr);
+            char *l2 = NEXT_LINE();
             if (!l2) break;
             char *f[9], *g[9];
             int nf = split_tabs(line2, f, 9), ng = split_tabs(l2, g, 9);
@@ -514,6 +532,8 @@ done:
     if (rc != EMSAR_HOST_OK) { if (!acc) emsar_counts_free(c); return rc; }
     *out = c;
     return EMSAR_HOST_OK;
+#undef NEXT_LINE
+#undef LINE_OFFSET
 }
 
 /* ---- the ranges of a plain text file counted side by side ---------------------------------------------------------- */
@@ -523,7 +543,7 @@ typedef struct {
 } range_job;
 static void *range_main(void *a) {
     range_job *j = (range_job *)a;
-    j->rc = count_range(j->r, j->path, j->o, j->begin, j->end, &j->c, &j->got, j->err, sizeof j->err, NULL, NULL);
+    j->rc = count_range(j->r, j->path, j->o, j->begin, j->end, &j->c, &j->got, j->err, sizeof j->err, NULL, NULL, NULL);
     return NULL;
 }
 
@@ -582,7 +602,7 @@ typedef struct {
     pthread_mutex_t mu; pthread_cond_t cv_work, cv_free;
     bam_batch *work_head, *work_tail, *free_list;
     int closing;
-    const emsar_rsh *r; const emsar_aln_opts *o; const bamreader *master;
+    const emsar_rsh *r; const emsar_aln_opts *o; const bamreader *master;     /* master == NULL: the batches are text lines (count_text_parallel) */
     int64_t err_index; int rc; char err[256];                        /* the failing batch that comes first in the file */
 } bam_pool;
 typedef struct { bam_pool *pool; emsar_counts *c; int got; pthread_t th; int started; } bam_worker;
@@ -597,11 +617,17 @@ static void *bam_worker_main(void *a) {
         if (b) { P->work_head = b->next; if (!P->work_head) P->work_tail = NULL; }
         pthread_mutex_unlock(&P->mu);
         if (!b) return NULL;
-        bamreader view = *P->master;                                  /* header and refID -> tid table shared read-only */
-        view.f = NULL; view.pf = NULL; view.buf = NULL; view.cap = 0;
-        view.mem = b->buf; view.mem_n = b->n; view.mem_pos = 0;
         emsar_counts *c = NULL; int got = 0; char err[256]; err[0] = 0;
-        int rc = w->c ? count_range(P->r, NULL, P->o, 0, -1, &c, &got, err, sizeof err, &view, w->c) : EMSAR_HOST_ERR_OOM;
+        int rc;
+        if (P->master) {
+            bamreader view = *P->master;                              /* header and refID -> tid table shared read-only */
+            view.f = NULL; view.pf = NULL; view.buf = NULL; view.cap = 0;
+            view.mem = b->buf; view.mem_n = b->n; view.mem_pos = 0;
+            rc = w->c ? count_range(P->r, NULL, P->o, 0, -1, &c, &got, err, sizeof err, &view, w->c, NULL) : EMSAR_HOST_ERR_OOM;
+        } else {
+            memtext view = {(char *)b->buf, b->n, 0};
+            rc = w->c ? count_range(P->r, NULL, P->o, 0, -1, &c, &got, err, sizeof err, NULL, w->c, &view) : EMSAR_HOST_ERR_OOM;
+        }
         w->got |= got;
         pthread_mutex_lock(&P->mu);
         if (rc != EMSAR_HOST_OK && (P->rc == EMSAR_HOST_OK || b->index < P->err_index)) {
@@ -808,6 +834,224 @@ static int count_bam_parallel(const emsar_rsh *r, const char *path, const emsar_
     return EMSAR_HOST_OK;
 }
 
+/* ---- text that cannot be cut into byte ranges (gzip, stdin, paired-end SAM, mates not named /1 /2) counted by the same pool ----
+ * The calling thread reads the lines (zlib inflates on it), copies them into batches and decides where a batch may end: before a unit
+ * (a record; paired-end: the two records the sequential loop would read together) that is KEPT and whose read id differs from the last
+ * kept unit's -- the same rule as for BAM above.  "Kept" and the id are worked out here from the first four fields with the tests of
+ * count_range (strand, '*' reference, mate orientation); a worker then runs count_range itself on its batches.  Whatever this thread
+ * cannot judge cheaply and exactly (a malformed line, an id longer than the buffers: the worker will report the error, or not) ends the
+ * cutting: everything after it goes into one last batch, which is always right. */
+/* the first four tab-separated fields of [p, p + n) and min(number of fields, need), in one pass */
+static int first_fields(const char *p, size_t n, int need, const char *f[4], size_t fl[4]) {
+    const char *e = p + n;
+    int nf = 0;
+    for (;;) {
+        const char *t = (const char *)memchr(p, '\t', (size_t)(e - p));
+        if (nf < 4) { f[nf] = p; fl[nf] = (size_t)((t ? t : e) - p); }
+        nf++;
+        if (!t || nf >= need) return nf;
+        p = t + 1;
+    }
+}
+static int span_atoi(const char *p, size_t n) { char b[32]; if (n > 31) n = 31; memcpy(b, p, n); b[n] = 0; return atoi(b); }
+#define TXT_ID_MAX 2048
+
+static int count_text_parallel(const emsar_rsh *r, const char *path, const emsar_aln_opts *o, emsar_counts **out, char *err, size_t errlen) {
+    const int nt = host_threads();
+    if (o->format == 2 || nt <= 1) return -100;
+    size_t batch_bytes = (size_t)4 << 20;
+    const char *e = getenv("EMSAR_HOST_RANGE_BYTES");                 /* tests: many batches on small files */
+    if (e && atoll(e) > 0) batch_bytes = (size_t)atoll(e);
+    const int named = path && path[0] && strcmp(path, "-") != 0;
+    if (named && !e) { struct stat st; if (stat(path, &st) == 0 && S_ISREG(st.st_mode) && st.st_size < (1 << 18)) return -100; }   /* small: not worth a pool */
+    /* Not for gzip: there the reader is zlib's inflate plus this thread's copy and field scan, which together cost more than the one-thread
+     * loop saves (tests/perf/text_pool_bench.py: 0.82 s against 0.61 s for 1.3 M gzipped bowtie records); EMSAR_HOST_TEXT_POOL=gz forces it
+     * (tests).  A named file is looked at through a reader of its own, so that the one-thread loop can still start from the beginning. */
+    const char *force = getenv("EMSAR_HOST_TEXT_POOL");
+    if (named && !(force && strcmp(force, "gz") == 0)) {
+        void *probe = emsar_lr_open(path);
+        if (!probe) { if (err) snprintf(err, errlen, "can't open alignment file %s", path); return EMSAR_HOST_ERR_IO; }
+        const int plain = emsar_lr_is_plain(probe);
+        emsar_lr_close(probe);
+        if (!plain) return -100;
+    }
+    void *lr = emsar_lr_open(path);
+    if (!lr) { if (err) snprintf(err, errlen, "can't open alignment file %s", path ? path : "-"); return EMSAR_HOST_ERR_IO; }
+
+    int rc = EMSAR_HOST_OK;
+    const int nq = 2 * nt;
+    bam_pool P;
+    memset(&P, 0, sizeof P);
+    pthread_mutex_init(&P.mu, NULL); pthread_cond_init(&P.cv_work, NULL); pthread_cond_init(&P.cv_free, NULL);
+    P.r = r; P.o = o; P.master = NULL; P.rc = EMSAR_HOST_OK;
+    bam_batch *all = (bam_batch *)calloc((size_t)nq, sizeof(*all));
+    bam_worker *w = (bam_worker *)calloc((size_t)nt, sizeof(*w));
+    char *prev = (char *)malloc(TXT_ID_MAX), *id1 = (char *)malloc(TXT_ID_MAX), *id2 = (char *)malloc(TXT_ID_MAX);
+    int n_started = 0;
+    if (!all || !w || !prev || !id1 || !id2) rc = EMSAR_HOST_ERR_OOM;
+    for (int i = 0; i < nq && rc == EMSAR_HOST_OK; i++) {
+        all[i].cap = batch_bytes + (1 << 16);
+        all[i].buf = (unsigned char *)malloc(all[i].cap);
+        if (!all[i].buf) rc = EMSAR_HOST_ERR_OOM;
+        all[i].next = P.free_list; P.free_list = &all[i];
+    }
+    for (int t = 0; t < nt && rc == EMSAR_HOST_OK; t++) {
+        w[t].pool = &P;
+        w[t].c = counts_new(r);
+        if (!w[t].c) { rc = EMSAR_HOST_ERR_OOM; break; }
+        if (pthread_create(&w[t].th, NULL, bam_worker_main, &w[t]) == 0) { w[t].started = 1; n_started++; }
+    }
+    if (rc == EMSAR_HOST_OK && n_started == 0) rc = EMSAR_HOST_ERR_OOM;
+
+    int64_t n_batches = 0;
+    if (rc == EMSAR_HOST_OK) {
+        bam_batch *cur = bam_batch_get(&P);
+        size_t fill = 0;
+        size_t prev_n = 0; int have_prev = 0;
+        int unsure = 0;                                               /* no more cuts from here on */
+        int have_1 = 0; size_t off_1 = 0, len_1 = 0;                   /* paired-end: the first record of the pair, in cur->buf */
+        char *line;
+        while ((line = emsar_lr_next(lr)) != NULL) {
+            const size_t ll = strlen(line);
+            if (fill + ll + 2 > cur->cap) {
+                const size_t want = (fill + ll + 2) * 2;
+                unsigned char *nb = (unsigned char *)realloc(cur->buf, want);
+                if (!nb) { rc = EMSAR_HOST_ERR_OOM; break; }
+                cur->buf = nb; cur->cap = want;
+            }
+            const size_t lo = fill;
+            memcpy(cur->buf + fill, line, ll); cur->buf[fill + ll] = '\n'; fill += ll + 1;
+            if (unsure) continue;
+            const char *L = (const char *)cur->buf + lo;
+            /* ---- the unit this line completes, if any: kept?, id, where it starts ---- */
+            int kept = 0; size_t unit = lo; const char *id = NULL; size_t idn = 0;
+            const char *F[4]; size_t FN[4];
+            if (o->format == 1 && !have_1 && L[0] == '@') continue;   /* SAM header line: skipped by the loop */
+            if (o->format == 1 && have_1 && ll > 0 && L[0] == '@') {  /* a header line where the mate should be ends the sequential loop (count_range: st == 0) */
+                fill = lo;                                            /* nothing from here on is read */
+                break;
+            }
+            const int need = o->format == 1 ? 11 : 7;
+            if (first_fields(L, ll, need, F, FN) < need || FN[0] >= TXT_ID_MAX - 1 || FN[1] == 0) { unsure = 1; continue; }
+            const char *f0 = F[0], *f1 = F[1], *f2 = F[2], *f3 = F[3];
+            const size_t n0 = FN[0], n1 = FN[1], n2 = FN[2], n3 = FN[3];
+            if (!o->pe) {
+                if (o->format == 1) {
+                    if (n2 == 1 && f2[0] == '*') continue;            /* unaligned: skipped */
+                    const char strand = (span_atoi(f1, n1) & 0x10) ? '-' : '+';
+                    kept = !(o->strand != 0 && o->strand != strand);
+                    idn = n0 < 1023 ? n0 : 1023;                      /* samrec.qname holds 1023 characters */
+                } else {
+                    kept = !(o->strand != 0 && o->strand != f1[0]);
+                    idn = n0;
+                }
+                id = f0;
+            } else if (o->format == 1) {                              /* paired-end SAM: an unaligned record is skipped singly, an aligned one is read with its successor */
+                if (!have_1) {
+                    if (n2 == 1 && f2[0] == '*') continue;
+                    have_1 = 1; off_1 = lo; len_1 = ll;
+                    continue;
+                }
+                have_1 = 0; unit = off_1;
+                const char *M = (const char *)cur->buf + off_1;
+                const char *G4[4]; size_t GN[4];
+                if (first_fields(M, len_1, 4, G4, GN) < 4) { unsure = 1; continue; }
+                const char *g0 = G4[0], *g1 = G4[1], *g3 = G4[3];
+                const size_t m0 = GN[0], m1 = GN[1], m3 = GN[3];
+                const int fl1 = span_atoi(g1, m1), fl2 = span_atoi(f1, n1), q1 = span_atoi(g3, m3) - 1, q2 = span_atoi(f3, n3) - 1;
+                int p1, p2; char s1, s2;
+                if ((fl1 & 0x40) && (fl2 & 0x80)) { p1 = q1; p2 = q2; s1 = (fl1 & 0x10) ? '-' : '+'; s2 = (fl2 & 0x10) ? '-' : '+'; }
+                else if ((fl2 & 0x40) && (fl1 & 0x80)) { p1 = q2; p2 = q1; s1 = (fl2 & 0x10) ? '-' : '+'; s2 = (fl1 & 0x10) ? '-' : '+'; }
+                else { unsure = 1; continue; }                        /* "mates are not grouped": the worker says so */
+                if (p2 > p1) kept = !(o->strand == '-') && (s1 == '+' && s2 == '-');
+                else kept = !(o->strand == '+') && (s1 == '-' && s2 == '+');
+                id = g0; idn = m0 < 1023 ? m0 : 1023;
+            } else {                                                  /* paired-end bowtie: two records at a time */
+                if (!have_1) { have_1 = 1; off_1 = lo; len_1 = ll; continue; }
+                have_1 = 0; unit = off_1;
+                const char *M = (const char *)cur->buf + off_1;
+                const char *G4[4]; size_t GN[4];
+                if (first_fields(M, len_1, 7, G4, GN) < 7 || GN[0] >= TXT_ID_MAX - 1 || GN[1] == 0) { unsure = 1; continue; }
+                const char *g0 = G4[0], *g1 = G4[1], *g2 = G4[2], *g3 = G4[3];
+                const size_t m0 = GN[0], m2 = GN[2], m3 = GN[3];
+                memcpy(id1, g0, m0); id1[m0] = 0; memcpy(id2, f0, n0); id2[n0] = 0;   /* record 1 = f of count_range, record 2 = g */
+                const int idlen = mate_id_len(id1, id2);
+                if (idlen == 0) { unsure = 1; continue; }             /* "mate read IDs don't match": the worker says so */
+                if (m2 == n2 && memcmp(g2, f2, n2) == 0) {            /* mates on one transcript; else no alignment */
+                    /* the reference's swap (count_range): record 2 is treated as mate 1 */
+                    const int p1 = span_atoi(f3, n3), p2 = span_atoi(g3, m3);
+                    const char s1 = f1[0], s2 = g1[0];
+                    if (p2 > p1) kept = !(o->strand == '-') && (s1 == '+' && s2 == '-');
+                    else kept = !(o->strand == '+') && (s1 == '-' && s2 == '+');
+                }
+                id = g0; idn = (size_t)idlen < 1023 ? (size_t)idlen : 1023;
+            }
+            if (!kept) continue;
+            const int new_group = !have_prev || idn != prev_n || memcmp(prev, id, idn) != 0;
+            memcpy(prev, id, idn); prev_n = idn; have_prev = 1;      /* (id points into cur->buf: copied before the buffer changes hands) */
+            if (unit >= batch_bytes && new_group) {                   /* the unit opens the next batch: the tail of the buffer moves there */
+                const size_t moved = fill - unit;
+                bam_batch *nb = bam_batch_get(&P);
+                if (moved + 2 > nb->cap) {
+                    unsigned char *g = (unsigned char *)realloc(nb->buf, moved + (1 << 16));
+                    if (!g) { bam_batch_put(&P, nb); rc = EMSAR_HOST_ERR_OOM; break; }
+                    nb->buf = g; nb->cap = moved + (1 << 16);
+                }
+                memcpy(nb->buf, cur->buf + unit, moved);
+                cur->n = unit; cur->index = n_batches++;
+                bam_batch_put(&P, cur);
+                cur = nb; fill = moved;
+                pthread_mutex_lock(&P.mu);
+                const int failed = P.rc != EMSAR_HOST_OK;
+                pthread_mutex_unlock(&P.mu);
+                if (failed) { fill = 0; break; }                      /* a batch already failed: whatever follows cannot come first */
+            }
+        }
+        cur->n = rc == EMSAR_HOST_OK ? fill : 0;
+        cur->index = n_batches++;
+        bam_batch_put(&P, cur);
+    }
+    pthread_mutex_lock(&P.mu);
+    P.closing = 1;
+    pthread_cond_broadcast(&P.cv_work);
+    pthread_mutex_unlock(&P.mu);
+    for (int t = 0; t < nt; t++) if (w && w[t].started) pthread_join(w[t].th, NULL);
+    emsar_lr_close(lr);
+
+    emsar_counts *c = NULL;
+    int got = 0;
+    if (rc == EMSAR_HOST_OK && P.rc != EMSAR_HOST_OK) { rc = P.rc; if (err) snprintf(err, errlen, "%s", P.err); }
+    if (rc == EMSAR_HOST_ERR_OOM && err) snprintf(err, errlen, "out of memory");
+    for (int t = 0; rc == EMSAR_HOST_OK && o->collapse && t < nt; t++)
+        if (w[t].c && batch_flush(r, o, w[t].c) != 0) { rc = EMSAR_HOST_ERR_IO; if (err) snprintf(err, errlen, "the collapse of read-level rows failed"); }
+    if (rc == EMSAR_HOST_OK) {
+        for (int t = 0; t < nt && rc == EMSAR_HOST_OK; t++) {
+            got |= w[t].got;
+            if (!c) { c = w[t].c; w[t].c = NULL; continue; }
+            counts_add(c, w[t].c);
+            if (w[t].c->readlength != r->hdr_readlength) {            /* learnt from the data (paired-end, header says -1) */
+                if (c->readlength == r->hdr_readlength) c->readlength = w[t].c->readlength;
+                else if (c->readlength != w[t].c->readlength) {
+                    rc = EMSAR_HOST_ERR_FORMAT;
+                    if (err) snprintf(err, errlen, "paired-end data with variable read length is not supported");
+                }
+            }
+        }
+        if (rc == EMSAR_HOST_OK && !got) {
+            rc = EMSAR_HOST_ERR_FORMAT;
+            if (err) snprintf(err, errlen, "no usable alignment in %s (the reference stops with 'NULL alignment list')", path ? path : "-");
+        }
+    }
+    if (getenv("EMSAR_HOST_DEBUG")) fprintf(stderr, "emsar_count_alignments: text, %lld batch(es) on %d thread(s)\n", (long long)n_batches, n_started);
+    for (int t = 0; w && t < nt; t++) emsar_counts_free(w[t].c);
+    for (int i = 0; all && i < nq; i++) free(all[i].buf);
+    free(all); free(w); free(prev); free(id1); free(id2);
+    pthread_mutex_destroy(&P.mu); pthread_cond_destroy(&P.cv_work); pthread_cond_destroy(&P.cv_free);
+    if (rc != EMSAR_HOST_OK) { emsar_counts_free(c); return rc; }
+    *out = c;
+    return EMSAR_HOST_OK;
+}
+
 int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln_opts *o, emsar_counts **out,
                            char *err, size_t errlen) {
     *out = NULL;
@@ -820,7 +1064,9 @@ int emsar_count_alignments(const emsar_rsh *r, const char *path, const emsar_aln
     int rc = EMSAR_HOST_OK, got = 0;
     if (getenv("EMSAR_HOST_DEBUG")) fprintf(stderr, "emsar_count_alignments: %d range(s) over %lld bytes\n", nt, (long long)size);
     if (nt <= 1) {
-        rc = count_range(r, path, o, 0, -1, out, &got, err, errlen, NULL, NULL);
+        const int prc = count_text_parallel(r, path, o, out, err, errlen);       /* gzip, stdin, paired-end SAM: one reader, a pool of counters */
+        if (prc != -100) return prc;
+        rc = count_range(r, path, o, 0, -1, out, &got, err, errlen, NULL, NULL, NULL);
         if (rc == EMSAR_HOST_OK && !got) {
             emsar_counts_free(*out); *out = NULL;
             if (err) snprintf(err, errlen, "no usable alignment in %s (the reference stops with 'NULL alignment list')", path);

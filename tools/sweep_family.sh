@@ -19,11 +19,17 @@ def run(env):
     ms = min(dev.run_passes(200) / 200 for _ in range(3))
     print(env, "ms/pass %.4f" % ms, "units", i["n_units"], "tiles", i["n_chunks"], "padded", i["padded_entries"], "entries", i["tiled_entries"], "far", i["far_entries"],
           "stored MB %.1f" % (i["stored_bytes_per_pass"] / 1e6), flush=True)
-for f in ("0", "10", "20", "35", "50"):
-    run({"EMSAR_HIP_TAIL_SPLIT": f})
+for rep in range(2):
+    run({})
+    for f in ("10", "20", "30"):
+        run({"EMSAR_HIP_TAIL_SPLIT": f})
+for e in ({"EMSAR_HIP_UNIT_TILES_MAX": "2"}, {"EMSAR_HIP_UNIT_TILES_MAX": "4", "EMSAR_HIP_UNIT_FAR_SOFT": "200"}, {"EMSAR_HIP_UNIT_FAR_SOFT": "120"}, {"EMSAR_HIP_UNIT_FAR_SOFT": "200"}, {}):
+    run(e)
 s = synth.make_config("cfg3", 1.0, "window")
 print("window law", flush=True)
-for f in ("0", "10", "20", "35"):
-    run({"EMSAR_HIP_TAIL_SPLIT": f})
+for rep in range(2):
+    run({})
+    for f in ("10", "20"):
+        run({"EMSAR_HIP_TAIL_SPLIT": f})
 PY
 cat $O/sweep.txt
