@@ -899,6 +899,25 @@ inline int build_tiled(int64_t n_rows, int32_t n_tx, const uint64_t *row_ptr_in,
         if (n > 0) fprintf(stderr, "build_tiled: per slice %.2f forward columns (%.0f %% > 8, %.0f %% > 16), %.2f backward segments per lane (%.0f %% > 8, %.0f %% > 16, %.0f %% > 24)\n",
                            sk / n, 100 * k8 / n, 100 * k16 / n, sm / n, 100 * m8 / n, 100 * m16 / n, 100 * m24 / n);
     }
+    if (dbg_t && !out.unit_first.empty()) {         // how evenly a unit's slices load the four waves of its workgroup: sum of the loads / (4 x the largest)
+        double eff = 0, wsum = 0, hist[13] = {0};
+        const size_t nu = out.unit_first.size() - 1;
+        for (size_t u = 0; u < nu; u++) {
+            int64_t load[kTileSlices] = {0, 0, 0, 0}, tot = 0; int ns = 0;
+            for (uint32_t t = out.unit_first[u]; t < out.unit_first[u + 1]; t++) {
+                const Tile &T = out.tiles[t];
+                for (int s2 = 0; s2 < (int)T.n_slices; s2++) {
+                    const int64_t w = (int64_t)T.k[s2] * kTileSliceRows + (int64_t)T.m[s2] * 64 * 12;
+                    load[(T.wave_of >> (2 * s2)) & 3] += w; tot += w; ns++;
+                }
+            }
+            const int64_t mx = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
+            eff += (double)tot / 4.0; wsum += (double)mx; hist[std::min(ns, 12)] += 1;
+        }
+        fprintf(stderr, "build_tiled: the four waves of a unit are busy %.3f of the unit's longest wave on average; units by number of slices 1..12:", eff / wsum);
+        for (int i = 1; i <= 12; i++) fprintf(stderr, " %.0f", hist[i]);
+        fprintf(stderr, "\n");
+    }
     const int ext = check_tiled_extents(out);       // nothing reaches the device unless every descriptor stays inside its arrays
     return ext == 0 ? 0 : ext;
 }
